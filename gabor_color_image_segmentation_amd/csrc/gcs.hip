@@ -1,0 +1,585 @@
+// libgcs — gfx950 (MI355X) kernels for the Gabor-bank + k-means segmenter path and their
+// C ABI (include/gcs.h). Arithmetic: SPEC.md (exact integers). The reference ships no code
+// for this path; the slot filled is /root/reference/BSD_metrics/script.py:30.
+//
+// Kernels
+//   gabor_mfma_kernel   im2col GEMM on v_mfma_i32_32x32x32_i8: A = packed 2-digit int8 taps
+//                       (rows = filter x {re_lo,re_hi,im_lo,im_hi}), B = (pixel-128) windows
+//                       built from an LDS tile by dword reads + v_alignbyte, exact int32
+//                       accumulate, fused epilogue (digit recombine, >>shift, |.|^2, isqrt)
+//                       -> uint16 feature planes.
+//   kmeans_assign_kernel exact integer argmin via fp32 byte-digit FMAs (all partial sums
+//                       < 2^24, hence exact), LDS-replicated u32 accumulators, per-workgroup
+//                       partial slabs (no global atomics, deterministic).
+//   kmeans_reduce / finalize / init / unpack / widen: small helpers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gcs.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------- errors
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+static int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return GCS_EHIP;
+}
+#define GCS_CHECK_LAUNCH(what)                          \
+    do {                                                \
+        hipError_t e_ = hipGetLastError();              \
+        if (e_ != hipSuccess) return hip_fail(e_, what); \
+    } while (0)
+
+extern "C" int gcs_abi_version(void) { return GCS_ABI_VERSION; }
+extern "C" const char *gcs_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------- geometry (host)
+static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+static inline int mtiles(int F) { return (F + 7) / 8; }
+
+extern "C" size_t gcs_bank_packed_bytes(int F) { return F > 0 ? (size_t)mtiles(F) * 8 * 64 * 16 : 0; }
+extern "C" size_t gcs_bank_bias_count(int F) { return F > 0 ? (size_t)mtiles(F) * 8 : 0; }
+extern "C" size_t gcs_feature_pitch(int W) { return W > 0 ? (size_t)round_up(W, 8) : 0; }
+extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int D) {
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+    return (size_t)B * D * H * gcs_feature_pitch(W) * sizeof(uint16_t);
+}
+extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * H * gcs_feature_pitch(W);
+}
+// Workgroups (= partial-sum rows) per image of the assign pass. Bounded so that one
+// workgroup's uint32 LDS accumulators cannot overflow (<= 65536 pixels x 46341).
+extern "C" size_t gcs_kmeans_parts_per_image(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    size_t px = (size_t)H * gcs_feature_pitch(W);
+    size_t need = (px + 65535) / 65536;
+    size_t want = (px + 8191) / 8192; // ~8K pixels per workgroup
+    if (want > 16) want = 16;
+    return need > want ? need : (want ? want : 1);
+}
+extern "C" size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k) {
+    if (B <= 0 || D <= 0 || k <= 0) return 0;
+    return (size_t)B * gcs_kmeans_parts_per_image(H, W) * k * (D + 1) * sizeof(uint64_t);
+}
+
+// ------------------------------------------------------------------------ bank pack (host)
+// A-fragment of v_mfma_i32_32x32x32_i8: lane l = (r = l&31, h = l>>5) supplies row r of the
+// 32-row tile, 16 consecutive k. We bind k-slot (kk, h, j) to tap (dy = 2*kk + h, dx = j) of
+// a 16x16 frame whose row 15 / column 15 are zero; both operands use the same binding, so
+// only "A row = lane&31, B col = lane&31" and the C/D map (cdna guide §3) are relied on.
+// Row r of tile mt = filter 8*mt + r/4, part r%4 in {re_lo, re_hi, im_lo, im_hi}: the four
+// parts of one filter land in one lane's accumulator quad (rows 4g..4g+3).
+extern "C" int gcs_bank_pack(const int16_t *tapq, int F, int ks, int8_t *packed, int32_t *bias) {
+    if (!tapq || !packed || !bias) return fail(GCS_EINVAL, "gcs_bank_pack: NULL pointer");
+    if (F <= 0) return fail(GCS_EINVAL, "gcs_bank_pack: n_filters must be > 0");
+    if (ks < 1 || ks > GCS_KSIZE_MAX || (ks & 1) == 0)
+        return fail(GCS_EINVAL, "gcs_bank_pack: ksize must be odd and <= 15");
+    const int MT = mtiles(F);
+    const int off = (GCS_KSIZE_MAX - ks) / 2; // centre smaller kernels in the 15x15 frame
+    memset(packed, 0, gcs_bank_packed_bytes(F));
+    memset(bias, 0, gcs_bank_bias_count(F) * sizeof(int32_t));
+    for (int f = 0; f < F; ++f) {
+        long s_re = 0, s_im = 0;
+        for (int t = 0; t < ks * ks; ++t) {
+            s_re += tapq[((size_t)f * 2 + 0) * ks * ks + t];
+            s_im += tapq[((size_t)f * 2 + 1) * ks * ks + t];
+        }
+        if (s_im != 0) return fail(GCS_EINVAL, "gcs_bank_pack: imaginary taps must sum to zero");
+        bias[f] = (int32_t)(128 * s_re);
+    }
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kk = 0; kk < 8; ++kk)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, h = lane >> 5;
+                const int f = 8 * mt + r / 4, part = r & 3;
+                int8_t *dst = packed + (((size_t)mt * 8 + kk) * 64 + lane) * 16;
+                if (f >= F) continue;
+                const int dy = 2 * kk + h - off;
+                if (dy < 0 || dy >= ks) continue;
+                for (int j = 0; j < 16; ++j) {
+                    const int dx = j - off;
+                    if (dx < 0 || dx >= ks) continue;
+                    const int q = tapq[(((size_t)f * 2 + (part >> 1)) * ks + dy) * ks + dx];
+                    if (q > 32639 || q < -32639)
+                        return fail(GCS_EINVAL, "gcs_bank_pack: tap outside two-digit range");
+                    const int lo = ((q + 128) & 255) - 128;
+                    const int hi = (q - lo) >> 8;
+                    dst[j] = (int8_t)((part & 1) ? hi : lo);
+                }
+            }
+    return GCS_OK;
+}
+
+// ================================================================================ Gabor
+constexpr int G_TW = 64;            // output tile width  (4 lanes-in-x * 16 shifts)
+constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
+constexpr int G_HALO = 7;
+constexpr int G_LROWS = G_TH + 15;  // 47 rows: halo 14 + the zero-tap row 15
+constexpr int G_LPITCH = 96;        // bytes per LDS tile row (>= 64 + 16 + 12)
+constexpr int G_LCOLS = G_TW + 15;  // 79 columns carry image data
+
+__device__ __forceinline__ int reflect_clamp(int i, int n) {
+    if (i < 0) i = -1 - i;
+    if (i >= n) i = 2 * n - 1 - i;
+    return min(max(i, 0), n - 1); // only reached for pixels whose outputs are not stored
+}
+
+// floor(sqrt(n)) for n < 2^31, exact: v_sqrt_f32 (1 ulp) biased low by (1-2^-20) lands in
+// {floor-1, floor}; one integer test fixes it (SPEC.md §3).
+__device__ __forceinline__ unsigned isqrt31(unsigned n) {
+    const float r = __builtin_amdgcn_sqrtf((float)n) * 0.99999905f;
+    unsigned q = (unsigned)r;
+    const unsigned q1 = q + 1u;
+    q += (__umul24(q1, q1) <= n) ? 1u : 0u;
+    return q;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
+    const uint8_t *__restrict__ img, int H, int W, const int8_t *__restrict__ apack,
+    const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats,
+    int pitch, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[3][G_LROWS][G_LPITCH];
+    __shared__ __attribute__((aligned(16))) int8_t s_a[MT * 8 * 64 * 16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * G_TH, x0 = tx * G_TW;
+    const int D = 3 * F;
+
+    // ---- stage: A fragments (16 B per lane, lane-linear) and the 3-channel image tile
+    {
+        const v4i *src = reinterpret_cast<const v4i *>(apack + (size_t)mt0 * 8 * 64 * 16);
+        v4i *dst = reinterpret_cast<v4i *>(s_a);
+        for (int i = tid; i < MT * 8 * 64; i += 256) dst[i] = src[i];
+        const uint8_t *ib = img + (size_t)b * H * W * 3;
+        for (int i = tid; i < G_LROWS * G_LPITCH; i += 256) {
+            const int row = i / G_LPITCH, col = i % G_LPITCH;
+            int8_t v0 = 0, v1 = 0, v2 = 0;
+            if (col < G_LCOLS) {
+                const int gy = reflect_clamp(y0 - G_HALO + row, H);
+                const int gx = reflect_clamp(x0 - G_HALO + col, W);
+                const uint8_t *p = ib + ((size_t)gy * W + gx) * 3;
+                v0 = (int8_t)(p[0] ^ 0x80);
+                v1 = (int8_t)(p[1] ^ 0x80);
+                v2 = (int8_t)(p[2] ^ 0x80);
+            }
+            s_tile[0][row][col] = v0;
+            s_tile[1][row][col] = v1;
+            s_tile[2][row][col] = v2;
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, h = lane >> 5;
+    const int li = r & 3, lyy = r >> 2;
+    const int oy = y0 + wave * 8 + lyy; // this lane's output row
+    if (y0 + wave * 8 >= H) return;     // whole wave outside the image (no barrier follows)
+
+    int bias_v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_v[mt][g] = bias[8 * (mt0 + mt) + 2 * g + h];
+
+
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 16*li + 4*q
+            int win[8][5];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int *rp = reinterpret_cast<const int *>(
+                    &s_tile[c][wave * 8 + lyy + 2 * kk + h][16 * li + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
+            }
+            unsigned outp[MT][4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // B fragments of pixel shift s = 4q + t: bytes [t, t+16) of each 20-byte window
+                v4i bf[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[kk][j] = (t == 0) ? win[kk][j]
+                                             : (int)__builtin_amdgcn_alignbyte((unsigned)win[kk][j + 1],
+                                                                               (unsigned)win[kk][j], t);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    // opaque copy: keeps the (loop-invariant) A-fragment LDS reads here instead
+                    // of hoisted out of every loop into 96 VGPRs
+                    unsigned aoff = (unsigned)(mt * 8 * 64 + lane) * 16u;
+                    asm volatile("" : "+v"(aoff));
+                    const v4i *ap = reinterpret_cast<const v4i *>(s_a + aoff);
+                    v16i acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = ((e & 3) == 0) ? bias_v[mt][e >> 2] : 0;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[kk * 64], bf[kk], acc, 0, 0, 0);
+                    // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int a_re = ((acc[4 * g + 1] << 8) + acc[4 * g + 0]) >> shift;
+                        const int a_im = ((acc[4 * g + 3] << 8) + acc[4 * g + 2]) >> shift;
+                        const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                        const unsigned m = isqrt31(n);
+                        if ((t & 1) == 0)
+                            outp[mt][g][t >> 1] = m;
+                        else
+                            outp[mt][g][t >> 1] |= m << 16;
+                        // materialise now: otherwise hipcc sinks the whole epilogue into the
+                        // store branches and keeps every accumulator live until then
+                        asm volatile("" : "+v"(outp[mt][g][t >> 1]));
+                    }
+                }
+                // keep hipcc from building all four shifts' fragments up front (128 VGPRs)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // 4 consecutive pixels x = x0 + 16*li + 4*q .. +3 of row oy: one 8-byte store per filter
+            const int ox = x0 + 16 * li + 4 * q;
+            if (oy < H && ox < pitch) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int f = 8 * (mt0 + mt) + 2 * g + h;
+                        if (f < F) {
+                            uint16_t *dst =
+                                feats + (((size_t)b * D + (size_t)c * F + f) * H + oy) * pitch + ox;
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(outp[mt][g][0], outp[mt][g][1]);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const int8_t *packed,
+                                  const int32_t *bias, int F, int shift, uint16_t *feats,
+                                  gcs_stream_t stream) {
+    if (!img || !packed || !bias || !feats) return fail(GCS_EINVAL, "gcs_gabor_features: NULL pointer");
+    if (B <= 0 || F <= 0) return fail(GCS_EINVAL, "gcs_gabor_features: B and n_filters must be > 0");
+    if (H < 8 || W < 8) return fail(GCS_EINVAL, "gcs_gabor_features: H and W must be >= 8");
+    if (shift < 0 || shift > 23) return fail(GCS_EINVAL, "gcs_gabor_features: shift out of range");
+    if (B > 65535) return fail(GCS_EINVAL, "gcs_gabor_features: B too large for one launch");
+    const int pitch = (int)gcs_feature_pitch(W);
+    const int tiles_x = (W + G_TW - 1) / G_TW, tiles_y = (H + G_TH - 1) / G_TH;
+    const dim3 grid(tiles_x * tiles_y, B), block(256);
+    const int MT = mtiles(F);
+    for (int mt0 = 0; mt0 < MT; mt0 += 3) {
+        const int n = MT - mt0 >= 3 ? 3 : MT - mt0;
+        if (n == 3)
+            hipLaunchKernelGGL(gabor_mfma_kernel<3>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+                               F, shift, feats, pitch, tiles_x);
+        else if (n == 2)
+            hipLaunchKernelGGL(gabor_mfma_kernel<2>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+                               F, shift, feats, pitch, tiles_x);
+        else
+            hipLaunchKernelGGL(gabor_mfma_kernel<1>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+                               F, shift, feats, pitch, tiles_x);
+        GCS_CHECK_LAUNCH("gcs_gabor_features");
+    }
+    return GCS_OK;
+}
+
+// ------------------------------------------------------------------------------- unpack
+__global__ void unpack_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, size_t planes,
+                              uint16_t *__restrict__ out) {
+    const size_t n = planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pl = i / ((size_t)H * W);
+        const int rem = (int)(i % ((size_t)H * W));
+        out[i] = feats[(pl * H + rem / W) * pitch + rem % W];
+    }
+}
+
+extern "C" int gcs_features_unpack(const uint16_t *feats, int B, int H, int W, int D, uint16_t *out,
+                                   gcs_stream_t stream) {
+    if (!feats || !out) return fail(GCS_EINVAL, "gcs_features_unpack: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return fail(GCS_EINVAL, "gcs_features_unpack: bad shape");
+    hipLaunchKernelGGL(unpack_kernel, dim3(2048), dim3(256), 0, stream, feats, H, W,
+                       (int)gcs_feature_pitch(W), (size_t)B * D, out);
+    GCS_CHECK_LAUNCH("gcs_features_unpack");
+    return GCS_OK;
+}
+
+// =============================================================================== k-means
+__global__ void kmeans_init_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, int D, int k,
+                                   uint16_t *__restrict__ cent) {
+    const int set = blockIdx.x; // image index == set index (n_sets == 1 -> image 0)
+    const long P = (long)H * W;
+    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
+        const int j = i / D, d = i % D;
+        const long p = ((2L * j + 1) * P) / (2L * k);
+        const int y = (int)(p / W), x = (int)(p % W);
+        cent[((size_t)set * k + j) * D + d] = feats[(((size_t)set * D + d) * H + y) * pitch + x];
+    }
+}
+
+extern "C" int gcs_kmeans_init(const uint16_t *feats, int B, int H, int W, int D, int k, int n_sets,
+                               uint16_t *cent, gcs_stream_t stream) {
+    if (!feats || !cent) return fail(GCS_EINVAL, "gcs_kmeans_init: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return fail(GCS_EINVAL, "gcs_kmeans_init: bad shape");
+    if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_init: k must be in 1..16");
+    if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_init: n_sets must be 1 or B");
+    hipLaunchKernelGGL(kmeans_init_kernel, dim3(n_sets), dim3(256), 0, stream, feats, H, W,
+                       (int)gcs_feature_pitch(W), D, k, cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_init");
+    return GCS_OK;
+}
+
+// Exact integer argmin with fp32 digit arithmetic: x = 256*xh + xl, c = 256*ch + cl (bytes);
+//   sum_d x*c = 65536*sum xh*ch + 256*sum (xh*cl + xl*ch) + sum xl*cl,
+// every partial sum stays below 2^24 over a chunk of <= 128 planes, so fp32 FMA is exact.
+// score_j = |c_j|^2 - 2 sum_d x_d c_jd (the |x|^2 term is common to all j).
+constexpr int KM_CHUNK = 128;
+
+template <int K>
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(
+    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int D,
+    int per_image, int parts, int R, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: cdig float [D][K][2] | cnorm int64 [K] | acc u32 [K][D+1][R]
+    float *cdig = reinterpret_cast<float *>(smem);
+    long long *cnorm = reinterpret_cast<long long *>(smem + (((size_t)D * K * 2 * 4 + 15) & ~(size_t)15));
+    unsigned *acc = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(cnorm) + ((K * 8 + 15) & ~15));
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
+    const int D1 = D + 1;
+
+    for (int i = tid; i < K * D; i += 256) {
+        const int j = i / D, d = i % D;
+        const unsigned cv = cset[i];
+        cdig[(d * K + j) * 2 + 0] = (float)(cv & 255u);
+        cdig[(d * K + j) * 2 + 1] = (float)(cv >> 8);
+    }
+    if (tid < K) {
+        long long s = 0;
+        for (int d = 0; d < D; ++d) {
+            const long long cv = cset[tid * D + d];
+            s += cv * cv;
+        }
+        cnorm[tid] = s;
+    }
+    for (int i = tid; i < K * D1 * R; i += 256) acc[i] = 0u;
+    __syncthreads();
+
+    const int ppr = pitch >> 1; // pixel pairs per row
+    const long npairs = (long)H * ppr;
+    const size_t plane = (size_t)H * pitch;
+    const uint16_t *fb = feats + (size_t)b * D * plane;
+    const int rep = tid & (R - 1);
+
+    for (long q = (long)part * 256 + tid; q < npairs; q += (long)parts * 256) {
+        const int y = (int)(q / ppr), x = 2 * (int)(q % ppr);
+        const size_t off = (size_t)y * pitch + x;
+        long long S[2][K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) S[0][j] = S[1][j] = 0;
+        for (int d0 = 0; d0 < D; d0 += KM_CHUNK) {
+            const int d1 = min(D, d0 + KM_CHUNK);
+            float a0[2][K], a1[2][K], a2[2][K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) a0[0][j] = a0[1][j] = a1[0][j] = a1[1][j] = a2[0][j] = a2[1][j] = 0.f;
+            for (int d = d0; d < d1; ++d) {
+                const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                const float xl0 = (float)(u & 255u), xh0 = (float)((u >> 8) & 255u);
+                const float xl1 = (float)((u >> 16) & 255u), xh1 = (float)(u >> 24);
+                const float *cd = cdig + d * K * 2;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float cl = cd[2 * j], ch = cd[2 * j + 1];
+                    a0[0][j] = fmaf(xl0, cl, a0[0][j]);
+                    a1[0][j] = fmaf(xh0, cl, fmaf(xl0, ch, a1[0][j]));
+                    a2[0][j] = fmaf(xh0, ch, a2[0][j]);
+                    a0[1][j] = fmaf(xl1, cl, a0[1][j]);
+                    a1[1][j] = fmaf(xh1, cl, fmaf(xl1, ch, a1[1][j]));
+                    a2[1][j] = fmaf(xh1, ch, a2[1][j]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    S[p][j] += ((long long)(unsigned)a2[p][j] << 16) + ((long long)(unsigned)a1[p][j] << 8) +
+                               (long long)(unsigned)a0[p][j];
+        }
+        int lab[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            long long best = cnorm[0] - 2 * S[p][0];
+            int bj = 0;
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                const long long sc = cnorm[j] - 2 * S[p][j];
+                if (sc < best) {
+                    best = sc;
+                    bj = j;
+                }
+            }
+            lab[p] = bj;
+        }
+        *reinterpret_cast<uint16_t *>(labels + ((size_t)b * H + y) * pitch + x) =
+            (uint16_t)(lab[0] | (lab[1] << 8));
+        // accumulate (second pass over this thread's planes; L2-resident)
+        const bool v0 = x < W, v1 = x + 1 < W;
+        if (v0) {
+            unsigned *a_0 = acc + (size_t)lab[0] * D1 * R + rep;
+            unsigned *a_1 = acc + (size_t)lab[1] * D1 * R + rep;
+            if (v1 && lab[0] == lab[1]) {
+                for (int d = 0; d < D; ++d) {
+                    const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                    atomicAdd(a_0 + d * R, (u & 0xffffu) + (u >> 16));
+                }
+                atomicAdd(a_0 + D * R, 2u);
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                    atomicAdd(a_0 + d * R, u & 0xffffu);
+                    if (v1) atomicAdd(a_1 + d * R, u >> 16);
+                }
+                atomicAdd(a_0 + D * R, 1u);
+                if (v1) atomicAdd(a_1 + D * R, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
+    for (int i = tid; i < K * D1; i += 256) {
+        uint64_t s = 0;
+        for (int rr = 0; rr < R; ++rr) s += acc[(size_t)i * R + rr];
+        prow[i] = s;
+    }
+}
+
+static size_t assign_lds_bytes(int D, int k, int R) {
+    size_t a = ((size_t)D * k * 2 * 4 + 15) & ~(size_t)15;
+    size_t c = ((size_t)k * 8 + 15) & ~(size_t)15;
+    return a + c + (size_t)k * (D + 1) * R * 4;
+}
+
+template <int K>
+static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int D, int n_sets,
+                         uint8_t *labels, uint64_t *partials, hipStream_t stream) {
+    const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+    int R = 32;
+    while (R > 1 && assign_lds_bytes(D, K, R) > 120 * 1024) R >>= 1;
+    const size_t lds = assign_lds_bytes(D, K, R);
+    if (lds > 160 * 1024) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k*D too large for LDS");
+    static size_t lds_granted = 0; // raise the dynamic-LDS cap once per instantiation
+    if (lds > lds_granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(assign)");
+        lds_granted = lds;
+    }
+    hipLaunchKernelGGL(kmeans_assign_kernel<K>, dim3(parts, B), dim3(256), lds, stream, feats, cent, H, W,
+                       (int)gcs_feature_pitch(W), D, n_sets == B ? 1 : 0, parts, R,
+                       labels, partials);
+    GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
+    return GCS_OK;
+}
+
+extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
+                                            int D, int k, int n_sets, uint8_t *labels, uint64_t *partials,
+                                            gcs_stream_t stream) {
+    if (!feats || !cent || !labels || !partials)
+        return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || B > 65535)
+        return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: bad shape");
+    if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
+    if (n_sets != 1 && n_sets != B)
+        return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
+    switch (k) {
+#define GCS_CASE(KK) \
+    case KK:         \
+        return launch_assign<KK>(feats, cent, B, H, W, D, n_sets, labels, partials, stream);
+        GCS_CASE(1) GCS_CASE(2) GCS_CASE(3) GCS_CASE(4) GCS_CASE(5) GCS_CASE(6) GCS_CASE(7) GCS_CASE(8)
+        GCS_CASE(9) GCS_CASE(10) GCS_CASE(11) GCS_CASE(12) GCS_CASE(13) GCS_CASE(14) GCS_CASE(15) GCS_CASE(16)
+#undef GCS_CASE
+    }
+    return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
+}
+
+// sums[set][e] = sum over the partial rows of the images in this set (fixed order).
+__global__ void kmeans_reduce_kernel(const uint64_t *__restrict__ partials, int rows_per_set, int row_len,
+                                     long long *__restrict__ sums) {
+    const int set = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= row_len) return;
+    const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
+    uint64_t s = 0;
+    for (int r = 0; r < rows_per_set; ++r) s += p[(size_t)r * row_len];
+    sums[(size_t)set * row_len + e] = (long long)s;
+}
+
+extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
+                                 int64_t *sums, gcs_stream_t stream) {
+    if (!partials || !sums) return fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX)
+        return fail(GCS_EINVAL, "gcs_kmeans_reduce: bad shape");
+    if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_reduce: n_sets must be 1 or B");
+    const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+    const int row_len = k * (D + 1);
+    const int rows_per_set = n_sets == B ? parts : B * parts;
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((row_len + 255) / 256, n_sets), dim3(256), 0, stream, partials,
+                       rows_per_set, row_len, reinterpret_cast<long long *>(sums));
+    GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
+    return GCS_OK;
+}
+
+__global__ void kmeans_finalize_kernel(const long long *__restrict__ sums, int n, int k, int D,
+                                       uint16_t *__restrict__ cent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = i % D, j = (i / D) % k, set = i / (D * k);
+    const long long *row = sums + ((size_t)set * k + j) * (D + 1);
+    const long long cnt = row[D];
+    if (cnt > 0) cent[i] = (uint16_t)((2 * row[d] + cnt) / (2 * cnt));
+}
+
+extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D, uint16_t *cent,
+                                   gcs_stream_t stream) {
+    if (!sums || !cent) return fail(GCS_EINVAL, "gcs_kmeans_finalize: NULL pointer");
+    if (n_sets <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_finalize: bad shape");
+    const int n = n_sets * k * D;
+    hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const long long *>(sums), n, k, D, cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_finalize");
+    return GCS_OK;
+}
+
+__global__ void widen_kernel(const uint8_t *__restrict__ labels, int H, int W, int pitch, size_t n,
+                             int32_t *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t by = i / W; // b*H + y
+        out[i] = labels[by * pitch + i % W];
+    }
+}
+
+extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream) {
+    if (!labels || !out) return fail(GCS_EINVAL, "gcs_labels_widen: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(GCS_EINVAL, "gcs_labels_widen: bad shape");
+    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, stream, labels, H, W, (int)gcs_feature_pitch(W),
+                       (size_t)B * H * W, out);
+    GCS_CHECK_LAUNCH("gcs_labels_widen");
+    return GCS_OK;
+}

@@ -1,0 +1,242 @@
+"""Host side of the segmenter slot: ``labels = segment(img)``.
+
+Mirrors the only interface the reference has for this path — the positional call at
+/root/reference/BSD_metrics/script.py:30 (``labels = slic(img, ...)``): ``img`` is the
+(H,W,3) uint8 array from script.py:25, the result is a fresh (H,W) integer array for
+metrics.__init__ (/root/reference/BSD_metrics/metrics.py:43-51). Errors are plain Python
+exceptions (script.py:19-38 catches nothing).
+
+PyTorch is plumbing only: device memory, the current HIP stream and torch.distributed
+(RCCL). All arithmetic runs in libgcs.so (csrc/gcs.hip) through the C ABI
+(include/gcs.h). There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib
+from .bank import GaborBank, make_bank
+
+_SLAB_BUDGET = 192 << 20   # per-image mode: keep a group's feature slab Infinity-Cache sized
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class HipOps:
+    """Thin pointer-passer over the C ABI for one device. Stateless apart from the bank."""
+
+    def __init__(self, bank: GaborBank, device):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.GcsError("no HIP device visible: the segmenter has no CPU fallback")
+        self.lib = _lib.load()
+        self.torch = torch
+        self.device = torch.device(device)
+        self.bank = bank
+        nf = bank.n_filters
+        packed = np.zeros(self.lib.gcs_bank_packed_bytes(nf), np.int8)
+        bias = np.zeros(self.lib.gcs_bank_bias_count(nf), np.int32)
+        tapq = np.ascontiguousarray(bank.tapq, np.int16)
+        _lib.check(self.lib.gcs_bank_pack(tapq.ctypes.data, nf, bank.ksize, packed.ctypes.data,
+                                          bias.ctypes.data), "gcs_bank_pack")
+        self.packed = torch.from_numpy(packed).to(self.device)
+        self.bias = torch.from_numpy(bias).to(self.device)
+
+    # ---- allocation helpers (bytes buffers; layouts are opaque, see gcs.h)
+    def empty_bytes(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.uint8, device=self.device)
+
+    def feature_slab(self, b, h, w):
+        return self.empty_bytes(self.lib.gcs_feature_slab_bytes(b, h, w, self.bank.n_features))
+
+    def label_slab(self, b, h, w):
+        return self.empty_bytes(self.lib.gcs_label_slab_bytes(b, h, w))
+
+    def partial_slab(self, b, h, w, k):
+        return self.empty_bytes(self.lib.gcs_kmeans_partial_bytes(b, h, w, self.bank.n_features, k))
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- device entry points
+    def gabor_features(self, imgs, feats):
+        b, h, w, _ = imgs.shape
+        _lib.check(self.lib.gcs_gabor_features(imgs.data_ptr(), b, h, w, self.packed.data_ptr(),
+                                               self.bias.data_ptr(), self.bank.n_filters,
+                                               self.bank.shift, feats.data_ptr(), self._stream()),
+                   "gcs_gabor_features")
+
+    def features_unpack(self, feats, b, h, w):
+        d = self.bank.n_features
+        out = self.torch.empty((b, d, h, w), dtype=self.torch.int16, device=self.device)
+        _lib.check(self.lib.gcs_features_unpack(feats.data_ptr(), b, h, w, d, out.data_ptr(),
+                                                self._stream()), "gcs_features_unpack")
+        return out
+
+    def kmeans_init(self, feats, b, h, w, k, n_sets, cent):
+        _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
+                                            cent.data_ptr(), self._stream()), "gcs_kmeans_init")
+
+    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials):
+        _lib.check(self.lib.gcs_kmeans_assign_accumulate(
+            feats.data_ptr(), cent.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
+            labels.data_ptr(), partials.data_ptr(), self._stream()), "gcs_kmeans_assign_accumulate")
+
+    def reduce(self, partials, b, h, w, k, n_sets, sums):
+        _lib.check(self.lib.gcs_kmeans_reduce(partials.data_ptr(), b, h, w, self.bank.n_features, k,
+                                              n_sets, sums.data_ptr(), self._stream()), "gcs_kmeans_reduce")
+
+    def finalize(self, sums, n_sets, k, cent):
+        _lib.check(self.lib.gcs_kmeans_finalize(sums.data_ptr(), n_sets, k, self.bank.n_features,
+                                                cent.data_ptr(), self._stream()), "gcs_kmeans_finalize")
+
+    def labels_widen(self, labels, b, h, w, out):
+        _lib.check(self.lib.gcs_labels_widen(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
+                   "gcs_labels_widen")
+
+    # centroid / sums tensors are ordinary torch tensors so torch.distributed can move them
+    def new_centroids(self, n_sets, k):
+        return self.torch.zeros((n_sets, k, self.bank.n_features), dtype=self.torch.int16, device=self.device)
+
+    def new_sums(self, n_sets, k):
+        return self.torch.zeros((n_sets, k, self.bank.n_features + 1), dtype=self.torch.int64,
+                                device=self.device)
+
+
+def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None):
+    """SPEC.md §4 schedule on one feature slab. ``mode``: 'per_image' or 'global'.
+
+    In 'global' mode with torch.distributed initialised, the init centroids come from
+    rank 0 (its image 0 is image 0 of the global batch) and the int64 sums are all-reduced
+    (RCCL on GPU, any order: integer sums are exact). One collective per Lloyd pass.
+    """
+    n_sets = b if mode == "per_image" else 1
+    dist = None
+    if mode == "global":
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized() and td.get_world_size(dist_group) > 1:
+            dist = td
+    ops.kmeans_init(feats, b, h, w, k, n_sets, cent)
+    if dist is not None:
+        dist.broadcast(cent, src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
+                       group=dist_group)
+    for t in range(n_iter):
+        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials)
+        if t < n_iter - 1:
+            ops.reduce(partials, b, h, w, k, n_sets, sums)
+            if dist is not None:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=dist_group)
+            ops.finalize(sums, n_sets, k, cent)
+
+
+class Segmenter:
+    """Reusable plan: bank on device + cached workspaces. ``__call__`` is the slot."""
+
+    def __init__(self, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=15, f_max=0.4,
+                 ratio=math.sqrt(2.0), bandwidth=1.0, device="cuda:0", ops=None):
+        if not (1 <= k <= _lib.K_MAX):
+            raise ValueError(f"k must be in 1..{_lib.K_MAX}")
+        if n_iter < 1:
+            raise ValueError("n_iter must be >= 1")
+        self.k, self.n_iter = int(k), int(n_iter)
+        self.bank = make_bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
+        self.ops = ops if ops is not None else HipOps(self.bank, device)
+        self._ws = {}
+
+    # ---- workspaces
+    def _workspace(self, g, h, w, mode):
+        key = (g, h, w, mode)
+        ws = self._ws.get(key)
+        if ws is None:
+            n_sets = g if mode == "per_image" else 1
+            ws = dict(feats=self.ops.feature_slab(g, h, w), labels=self.ops.label_slab(g, h, w),
+                      partials=self.ops.partial_slab(g, h, w, self.k),
+                      cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
+            self._ws = {key: ws}          # keep one shape resident
+        return ws
+
+    def group_size(self, b, h, w, mode):
+        if mode == "global":
+            return b
+        per_image = self.ops.lib.gcs_feature_slab_bytes(1, h, w, self.bank.n_features) \
+            if hasattr(self.ops, "lib") else 2 * self.bank.n_features * h * w
+        return max(1, min(b, _SLAB_BUDGET // max(1, per_image)))
+
+    # ---- device-resident API (used by bench.py: inputs already in HBM)
+    def segment_device(self, imgs, mode="per_image", out=None, dist_group=None, group=None):
+        """imgs: (B,H,W,3) uint8 device tensor -> (B,H,W) int32 device tensor."""
+        torch = _torch()
+        if imgs.dtype != torch.uint8 or imgs.dim() != 4 or imgs.shape[3] != 3:
+            raise ValueError("imgs must be a (B,H,W,3) uint8 tensor")
+        if mode not in ("per_image", "global"):
+            raise ValueError("mode must be 'per_image' or 'global'")
+        imgs = imgs.contiguous()
+        b, h, w, _ = imgs.shape
+        if h < 8 or w < 8:
+            raise ValueError("images must be at least 8x8")
+        if out is None:
+            out = torch.empty((b, h, w), dtype=torch.int32, device=imgs.device)
+        g = group or self.group_size(b, h, w, mode)
+        for g0 in range(0, b, g):
+            n = min(g, b - g0)
+            ws = self._workspace(n, h, w, mode) if n == g else self._tail_workspace(n, h, w, mode)
+            self.ops.gabor_features(imgs[g0:g0 + n], ws["feats"])
+            lloyd(self.ops, ws["feats"], n, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
+                  ws["cent"], ws["sums"], dist_group)
+            self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
+        return out
+
+    def _tail_workspace(self, n, h, w, mode):
+        n_sets = n if mode == "per_image" else 1
+        return dict(feats=self.ops.feature_slab(n, h, w), labels=self.ops.label_slab(n, h, w),
+                    partials=self.ops.partial_slab(n, h, w, self.k),
+                    cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
+
+    def features_device(self, imgs):
+        """Canonical (B,D,H,W) uint16 features as an int16 tensor (tests / debugging)."""
+        imgs = imgs.contiguous()
+        b, h, w, _ = imgs.shape
+        feats = self.ops.feature_slab(b, h, w)
+        self.ops.gabor_features(imgs, feats)
+        return self.ops.features_unpack(feats, b, h, w)
+
+    # ---- host API: the slot
+    def segment_batch(self, imgs: np.ndarray, mode="per_image") -> np.ndarray:
+        torch = _torch()
+        imgs = np.ascontiguousarray(imgs)
+        if imgs.dtype != np.uint8 or imgs.ndim != 4 or imgs.shape[3] != 3:
+            raise ValueError("imgs must be a (B,H,W,3) uint8 array")
+        dev = torch.from_numpy(imgs).to(self.ops.device)
+        return self.segment_device(dev, mode).cpu().numpy()
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("img must be an (H,W,3) uint8 array (skimage.io.imread of an RGB file)")
+        return self.segment_batch(img[None])[0]
+
+
+_default: dict = {}
+
+
+def _plan(kw) -> Segmenter:
+    key = tuple(sorted(kw.items()))
+    if key not in _default:
+        _default.clear()
+        _default[key] = Segmenter(**kw)
+    return _default[key]
+
+
+def segment(img, **kw) -> np.ndarray:
+    """Drop-in for ``slic(img, ...)`` at script.py:30: (H,W,3) uint8 -> (H,W) int32 labels 0..k-1."""
+    return _plan(kw)(img)
+
+
+def segment_batch(imgs, mode="per_image", **kw) -> np.ndarray:
+    """(B,H,W,3) uint8 -> (B,H,W) int32; equals stack([segment(i) for i in imgs]) in per_image mode."""
+    return _plan(kw).segment_batch(imgs, mode)

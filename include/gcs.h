@@ -1,0 +1,103 @@
+/* gcs.h — C ABI of libgcs.so: the MI355X (gfx950) Gabor-bank + k-means segmenter path.
+ *
+ * Drop-in boundary: the reference has NO plugin/operator/FFI registry for this path; its
+ * whole interface is one positional Python call,
+ *     labels = <callable>(img)            /root/reference/BSD_metrics/script.py:30
+ * with img (H,W,3) uint8 (script.py:25) and labels (H,W) integer consumed by
+ * metrics.__init__ (/root/reference/BSD_metrics/metrics.py:43-51). The functions below are
+ * what a binding for that slot calls underneath; INTEGRATION.md shows the
+ * ctypes stub. Arithmetic is defined by SPEC.md (exact integers).
+ *
+ * Conventions: every pointer named *_dev is device memory owned by the caller; nothing is
+ * allocated, freed or synchronised here (graph-capture safe); work is enqueued on `stream`
+ * (a hipStream_t; NULL = default stream). Return 0 on success, GCS_E* otherwise, with a
+ * thread-local message in gcs_last_error(). Not thread-safe per buffer.
+ */
+#ifndef GCS_H
+#define GCS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t *gcs_stream_t; /* == hipStream_t */
+
+enum {
+    GCS_OK = 0,
+    GCS_EINVAL = 1, /* bad argument (shape, range, NULL) */
+    GCS_EHIP = 2    /* HIP runtime error at launch */
+};
+
+#define GCS_ABI_VERSION 1
+#define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
+#define GCS_K_MAX 16     /* clusters */
+
+int gcs_abi_version(void);
+const char *gcs_last_error(void);
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
+
+/* Filters are padded to a multiple of 8 (one 32-row MFMA tile = 8 filters x {re,im} x
+ * {lo,hi} digits). Bytes of the packed A-operand image / number of int32 bias words. */
+size_t gcs_bank_packed_bytes(int n_filters);
+size_t gcs_bank_bias_count(int n_filters);
+
+/* Pack quantised taps tapq[F][2][ks][ks] (int16, SPEC.md §2) into the lane-linear int8
+ * A-fragments of v_mfma_i32_32x32x32_i8 and the per-filter bias 128*sum(tapq_re)
+ * (pixels are fed as img-128). Replaces nothing in the reference (bank absent). */
+int gcs_bank_pack(const int16_t *tapq, int n_filters, int ksize, int8_t *packed, int32_t *bias);
+
+/* Feature slab geometry: uint16 planes [B][D][H][pitch], pitch = W rounded up to 8 pixels.
+ * The slab is opaque to callers; gcs_features_unpack gives the canonical layout. */
+size_t gcs_feature_pitch(int W);
+size_t gcs_feature_slab_bytes(int B, int H, int W, int D);
+size_t gcs_label_slab_bytes(int B, int H, int W); /* uint8 [B][H][pitch] */
+/* uint64 partial-sum rows written by one assign pass: [B][parts][k][D+1]. */
+size_t gcs_kmeans_parts_per_image(int H, int W);
+size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
+
+/* ---- device entry points ---------------------------------------------------------------- */
+
+/* SPEC.md §3: img_dev [B][H][W][3] uint8 -> feats_dev slab, D = 3*F, d = c*F + f.
+ * Fills the slot's first stage (script.py:30). Requires H, W >= 8. */
+int gcs_gabor_features(const uint8_t *img_dev, int B, int H, int W, const int8_t *packed_dev,
+                       const int32_t *bias_dev, int n_filters, int shift, uint16_t *feats_dev,
+                       gcs_stream_t stream);
+
+/* Slab -> canonical [B][D][H][W] uint16 (tests / debugging). */
+int gcs_features_unpack(const uint16_t *feats_dev, int B, int H, int W, int D, uint16_t *out_dev,
+                        gcs_stream_t stream);
+
+/* SPEC.md §4 init. n_sets == B: per-image codebooks (set s from image s); n_sets == 1:
+ * global codebook from image 0. centroids_dev: uint16 [n_sets][k][D]. */
+int gcs_kmeans_init(const uint16_t *feats_dev, int B, int H, int W, int D, int k, int n_sets,
+                    uint16_t *centroids_dev, gcs_stream_t stream);
+
+/* SPEC.md §4 assign + per-workgroup partial sums (one streaming pass over the slab).
+ * labels_dev: label slab; partials_dev: gcs_kmeans_partial_bytes() bytes, fully
+ * overwritten (no zeroing needed). */
+int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
+                                 int H, int W, int D, int k, int n_sets, uint8_t *labels_dev,
+                                 uint64_t *partials_dev, gcs_stream_t stream);
+
+/* partials -> sums_dev int64 [n_sets][k][D+1] ([..][D] = count). Deterministic slab
+ * reduction (no float, no atomics). In global mode the caller all-reduces sums_dev across
+ * ranks (RCCL, int64 sum) between this call and gcs_kmeans_finalize. */
+int gcs_kmeans_reduce(const uint64_t *partials_dev, int B, int H, int W, int D, int k, int n_sets,
+                      int64_t *sums_dev, gcs_stream_t stream);
+
+/* SPEC.md §4 update: c = floor((2S + n) / (2n)), empty cluster keeps its centroid. */
+int gcs_kmeans_finalize(const int64_t *sums_dev, int n_sets, int k, int D,
+                        uint16_t *centroids_dev, gcs_stream_t stream);
+
+/* Label slab -> int32 [B][H][W] (the dtype handed to metrics.py:43). */
+int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *out_dev,
+                     gcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCS_H */
