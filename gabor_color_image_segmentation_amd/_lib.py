@@ -55,6 +55,13 @@ def load():
         raise GcsError(
             f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU "
             "fallback; run `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # One HIP runtime per process: import torch first so that libgcs.so's NEEDED
+    # libamdhip64.so.7 binds (by SONAME) to the runtime torch already loaded, instead of
+    # pulling a second copy from /opt/rocm that knows nothing of torch's streams/memory.
+    import torch
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch
