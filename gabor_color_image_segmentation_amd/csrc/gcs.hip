@@ -470,6 +470,226 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// One Lloyd pass on the matrix cores (D <= 79). Per 256-pixel tile, staged ONCE in LDS as
+// u16 planes (each byte offset by -128 so it is a signed MFMA digit):
+//   assign:  scores[(j,pat)][px] = A_pat[(j,pat)][k] * X[k][px] on v_mfma_i32_32x32x32_i8, k =
+//            (plane, byte). Patterns per cluster j: LL = cl*xl, M = ch*xl + cl*xh, HH = ch*xh, so
+//            sum_d x_d c_jd = LL + 256 M + 65536 HH exactly (int32 partials, int64 combine);
+//            argmin_j |c_j|^2 - 2 sum_d x_d c_jd, ties -> lowest j (SPEC.md §4).
+//   update:  sums[j][byte-plane] = onehot[j][px] * X[px][byte-plane] on v_mfma_i32_16x16x64_i8;
+//            one spare byte-plane is all ones and yields the counts. Accumulators live in
+//            registers for the whole workgroup; nothing but the tile load touches HBM.
+// The one-hot digit is 0x80 (= -128) to save a shift; it is divided out exactly at the end.
+constexpr int KP_TP = 256;                // pixels per tile: 4 waves x 64
+constexpr int KP_ROWS = 80;               // plane rows held in LDS
+constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
+constexpr int KP_DSTEPS = KP_ROWS / 16;   // assign K-steps: 16 planes = 32 byte-features each
+constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-planes each
+constexpr int KP_NST = KP_ROWS * (KP_TP / 8) / 256;  // 16-byte staging chunks per thread
+
+template <int KT>
+__global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
+    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int D,
+    int K, int per_image, int parts, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
+    __shared__ long long s_const[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
+    const int npix = H * pitch;
+    const int ntiles = (npix + KP_TP - 1) / KP_TP;
+    const uint16_t *fb = feats + (size_t)b * D * npix;
+
+    // ---- per-cluster constant: |c|^2 - 2*(offset terms of the -128 digits), exact int64
+    if (tid < 16) {
+        long long cst = 0;
+        if (tid < K) {
+            long long nrm = 0, scl = 0, sch = 0;
+            for (int d = 0; d < D; ++d) {
+                const long long c = cset[tid * D + d];
+                nrm += c * c;
+                scl += c & 255;
+                sch += c >> 8;
+            }
+            const long long q = 16384LL * D;
+            const long long g = (128 * scl - q) + 256 * (128 * (sch + scl) - 2 * q) + 65536 * (128 * sch - q);
+            cst = nrm - 2 * g;
+        }
+        s_const[tid] = cst;
+    }
+    // ---- assign A fragments: row r = 4*jj + pat of tile mt (cluster j = 8*mt + jj);
+    //      k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2, byte t&1)
+    v4i apat[KT][KP_DSTEPS];
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const int jj = r >> 2, pat = r & 3;
+#pragma unroll
+        for (int mt = 0; mt < KT; ++mt) {
+            const int j = 8 * mt + jj;
+#pragma unroll
+            for (int kk = 0; kk < KP_DSTEPS; ++kk) {
+                v4i f = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int d = 16 * kk + 8 * h + (t >> 1), bb = t & 1;
+                    int v = 0;
+                    if (j < K && d < D && pat < 3) {
+                        const int c = cset[j * D + d];
+                        const int cl = (c & 255) - 128, ch = (c >> 8) - 128;
+                        if (pat == 0) v = bb ? 0 : cl;
+                        if (pat == 1) v = bb ? cl : ch;
+                        if (pat == 2) v = bb ? ch : 0;
+                    }
+                    f[t >> 2] |= (v & 255) << (8 * (t & 3));
+                }
+                apat[mt][kk] = f;
+            }
+        }
+    }
+    v4i accu[KP_NT];
+#pragma unroll
+    for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
+
+    // ---- staging: chunk ci = tid + 256*i -> plane ci>>5, pixels 8*(ci&31) .. +7 of the tile
+    v4i st[KP_NST];
+    auto stage_load = [&](int tile) {
+        const int pp0 = tile * KP_TP;
+#pragma unroll
+        for (int i = 0; i < KP_NST; ++i) {
+            const int ci = tid + 256 * i;
+            const int d = ci >> 5, po = 8 * (ci & 31);
+            v4i v = {0, 0, 0, 0};
+            if (d < D && pp0 + po < npix) v = *reinterpret_cast<const v4i *>(fb + (size_t)d * npix + pp0 + po);
+            st[i] = v;
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < KP_NST; ++i) {
+            const int ci = tid + 256 * i;
+            const int d = ci >> 5, po = 8 * (ci & 31);
+            v4i v = st[i];
+            v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
+            *reinterpret_cast<v4i *>(&s_tile[d * KP_PITCH + po * 2]) = v;
+        }
+    };
+
+    const int un = lane & 15, ug = lane >> 4;             // update operand coordinates
+    const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
+    const int cnt_bp = 2 * D;                              // the all-ones byte-plane
+    const unsigned eqr = (unsigned)un * 0x01010101u;
+
+    int tile = part;
+    if (tile < ntiles) stage_load(tile);
+    for (; tile < ntiles; tile += parts) {
+        stage_write();
+        __syncthreads();
+        if (tile + parts < ntiles) stage_load(tile + parts);   // in flight during the MFMAs
+
+        const int pp0 = tile * KP_TP;
+        // -------- assign: two 32-pixel sub-tiles per wave
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int n = lane & 31, h = lane >> 5;
+            const int pl = wave * 64 + sub * 32 + n;
+            v16i acc[KT];
+#pragma unroll
+            for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][e] = 0;
+#pragma unroll
+            for (int kk = 0; kk < KP_DSTEPS; ++kk) {
+                const unsigned char *base = &s_tile[(16 * kk + 8 * h) * KP_PITCH + pl * 2];
+                v4i bf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned lo = *reinterpret_cast<const uint16_t *>(base + (2 * i) * KP_PITCH);
+                    const unsigned hi = *reinterpret_cast<const uint16_t *>(base + (2 * i + 1) * KP_PITCH);
+                    bf[i] = (int)(lo | (hi << 16));
+                }
+#pragma unroll
+                for (int mt = 0; mt < KT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat[mt][kk], bf, acc[mt], 0, 0, 0);
+            }
+            long long best = 0x7fffffffffffffffLL;
+            int bj = 255;
+#pragma unroll
+            for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j = 8 * mt + 2 * g + h;
+                    const long long t = (long long)acc[mt][4 * g] + ((long long)acc[mt][4 * g + 1] << 8) +
+                                        ((long long)acc[mt][4 * g + 2] << 16);
+                    const long long sc = s_const[j] - 2 * t;
+                    if (j < K && sc < best) {
+                        best = sc;
+                        bj = j;
+                    }
+                }
+            const long long pb = __shfl_xor(best, 32);
+            const int pj = __shfl_xor(bj, 32);
+            if (pb < best || (pb == best && pj < bj)) bj = pj;
+            const int pp = pp0 + pl;
+            if (h == 0) {
+                const bool valid = pp < npix && (pp % pitch) < W;
+                s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
+                if (pp < npix) labels[(size_t)b * npix + pp] = (uint8_t)bj;
+            }
+        }
+        // -------- update: one-hot MFMA over this wave's 64 pixels
+        {
+            const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
+            v4i oh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned x = (unsigned)lw[i] ^ eqr;                    // byte == 0 <=> label == un
+                const unsigned y = (x | 0x80808080u) - 0x01010101u;        // top bit clear <=> byte == 0
+                oh[i] = (int)(~y & 0x80808080u);                            // digit -128 where label == un
+            }
+#pragma unroll
+            for (int nt = 0; nt < KP_NT; ++nt) {
+                const int d = 8 * nt + (un >> 1);
+                const v4i *src = reinterpret_cast<const v4i *>(&s_tile[d * KP_PITCH + (wave * 64 + 16 * ug) * 2]);
+                const v4i w0 = src[0], w1 = src[1];
+                v4i bx;
+                bx[0] = (int)__builtin_amdgcn_perm((unsigned)w0[1], (unsigned)w0[0], usel);
+                bx[1] = (int)__builtin_amdgcn_perm((unsigned)w0[3], (unsigned)w0[2], usel);
+                bx[2] = (int)__builtin_amdgcn_perm((unsigned)w1[1], (unsigned)w1[0], usel);
+                bx[3] = (int)__builtin_amdgcn_perm((unsigned)w1[3], (unsigned)w1[2], usel);
+                if (16 * nt + un == cnt_bp) bx = v4i{0x01010101, 0x01010101, 0x01010101, 0x01010101};
+                accu[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx, accu[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row
+    int *red = reinterpret_cast<int *>(s_tile);               // [16][160]
+    for (int i = tid; i < 16 * KP_NT * 16; i += 256) red[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < KP_NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&red[(4 * ug + e) * (KP_NT * 16) + 16 * nt + un], accu[nt][e]);
+    __syncthreads();
+    const int D1 = D + 1;
+    uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
+    for (int i = tid; i < K * D1; i += 256) {
+        const int j = i / D1, e = i % D1;
+        const long long nj = -(long long)red[j * (KP_NT * 16) + cnt_bp] / 128;
+        long long out = nj;
+        if (e < D) {
+            const long long lo = -(long long)red[j * (KP_NT * 16) + 2 * e] / 128 + 128 * nj;
+            const long long hi = -(long long)red[j * (KP_NT * 16) + 2 * e + 1] / 128 + 128 * nj;
+            out = lo + 256 * hi;
+        }
+        prow[i] = (uint64_t)out;
+    }
+}
+
 static size_t assign_lds_bytes(int D, int k, int R) {
     size_t a = ((size_t)D * k * 2 * 4 + 15) & ~(size_t)15;
     size_t c = ((size_t)k * 8 + 15) & ~(size_t)15;
@@ -508,7 +728,20 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
     if (n_sets != 1 && n_sets != B)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
-    switch (k) {
+    if (D < KP_ROWS) { // matrix-core pass (the product path for every BASELINE bank with F <= 26)
+        const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+        const int pitch = (int)gcs_feature_pitch(W);
+        if ((long long)H * pitch > 0x7fffffffLL / 2) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large");
+        if (k <= 8)
+            hipLaunchKernelGGL(kmeans_pass_mfma_kernel<1>, dim3(parts, B), dim3(256), 0, stream, feats, cent, H, W,
+                               pitch, D, k, n_sets == B ? 1 : 0, parts, labels, partials);
+        else
+            hipLaunchKernelGGL(kmeans_pass_mfma_kernel<2>, dim3(parts, B), dim3(256), 0, stream, feats, cent, H, W,
+                               pitch, D, k, n_sets == B ? 1 : 0, parts, labels, partials);
+        GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
+        return GCS_OK;
+    }
+    switch (k) { // generic VALU pass for wider feature vectors
 #define GCS_CASE(KK) \
     case KK:         \
         return launch_assign<KK>(feats, cent, B, H, W, D, n_sets, labels, partials, stream);
@@ -519,16 +752,29 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
 }
 
-// sums[set][e] = sum over the partial rows of the images in this set (fixed order).
-__global__ void kmeans_reduce_kernel(const uint64_t *__restrict__ partials, int rows_per_set, int row_len,
-                                     long long *__restrict__ sums) {
+// sums[set][e] = sum over the partial rows of the images in this set. Integer sums: any
+// order gives the same bits. Block = 16 elements x 16 row slices, folded through LDS.
+__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
+                                                            int rows_per_set, int row_len,
+                                                            long long *__restrict__ sums) {
+    __shared__ uint64_t s_part[16][17];
     const int set = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= row_len) return;
-    const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
     uint64_t s = 0;
-    for (int r = 0; r < rows_per_set; ++r) s += p[(size_t)r * row_len];
-    sums[(size_t)set * row_len + e] = (long long)s;
+    if (e < row_len) {
+        const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
+#pragma unroll 4
+        for (int r = slice; r < rows_per_set; r += 16) s += p[(size_t)r * row_len];
+    }
+    s_part[slice][el] = s;
+    __syncthreads();
+    if (slice == 0 && e < row_len) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_part[i][el];
+        sums[(size_t)set * row_len + e] = (long long)t;
+    }
 }
 
 extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
@@ -540,7 +786,7 @@ extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, 
     const int parts = (int)gcs_kmeans_parts_per_image(H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((row_len + 255) / 256, n_sets), dim3(256), 0, stream, partials,
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
                        rows_per_set, row_len, reinterpret_cast<long long *>(sums));
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
     return GCS_OK;
