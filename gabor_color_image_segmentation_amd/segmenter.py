@@ -123,7 +123,9 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
             dist = td
     ops.kmeans_init(feats, b, h, w, k, n_sets, cent)
     if dist is not None:
-        dist.broadcast(cent, src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
+        # RCCL / gloo have no 16-bit integer type: move the centroid bytes
+        dist.broadcast(cent.view(ops.torch.uint8) if hasattr(ops, "torch") else cent.view(_torch().uint8),
+                       src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
                        group=dist_group)
     for t in range(n_iter):
         ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials)

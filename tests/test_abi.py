@@ -1,0 +1,127 @@
+"""The C-ABI library: loads, exports every symbol include/gcs.h declares, and its host-only
+entry points behave (no GPU compute is launched here)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from gabor_color_image_segmentation_amd import _lib, make_bank, split_digits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    return _lib.load()
+
+
+def test_header_and_library_agree(lib):
+    hdr = open(os.path.join(ROOT, "include", "gcs.h")).read()
+    declared = set(re.findall(r"\b(gcs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
+    assert lib.gcs_abi_version() == 1
+
+
+def test_no_torch_types_in_the_abi():
+    hdr = open(os.path.join(ROOT, "include", "gcs.h")).read()
+    assert "torch" not in hdr.lower().replace("pytorch-rocm", "") and "at::" not in hdr
+
+
+def test_geometry(lib):
+    assert lib.gcs_feature_pitch(481) == 488 and lib.gcs_feature_pitch(321) == 328 and lib.gcs_feature_pitch(8) == 8
+    assert lib.gcs_feature_slab_bytes(64, 321, 481, 72) == 64 * 72 * 321 * 488 * 2
+    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * 321 * 488
+    assert lib.gcs_bank_packed_bytes(24) == 3 * 8 * 64 * 16 and lib.gcs_bank_packed_bytes(1) == 8 * 64 * 16
+    assert lib.gcs_bank_bias_count(24) == 24 and lib.gcs_bank_bias_count(25) == 32
+    p = lib.gcs_kmeans_parts_per_image(321, 481)
+    assert 1 <= p <= 16 and 321 * 488 / p <= 65536
+    assert lib.gcs_kmeans_parts_per_image(2048, 2048) * 65536 >= 2048 * 2048
+    assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * 8 * 73 * 8
+    assert lib.gcs_feature_slab_bytes(0, 1, 1, 1) == 0
+
+
+def _pack(lib, bank):
+    nf = bank.n_filters
+    packed = np.zeros(lib.gcs_bank_packed_bytes(nf), np.int8)
+    bias = np.zeros(lib.gcs_bank_bias_count(nf), np.int32)
+    tq = np.ascontiguousarray(bank.tapq)
+    rc = lib.gcs_bank_pack(tq.ctypes.data, nf, bank.ksize, packed.ctypes.data, bias.ctypes.data)
+    return rc, packed, bias
+
+
+@pytest.mark.parametrize("kw", [{}, dict(n_scales=2, n_orient=3, ksize=7), dict(n_scales=1, n_orient=1, ksize=1),
+                                dict(n_scales=8, n_orient=8)])
+def test_bank_pack_layout(lib, kw):
+    """packed[mt][kk][lane][j] = digit(part) of tap (dy=2kk+h, dx=j) of filter 8mt + r/4 (gcs.hip)."""
+    bank = make_bank(**kw)
+    rc, packed, bias = _pack(lib, bank)
+    assert rc == 0
+    nf, ks = bank.n_filters, bank.ksize
+    lo, hi = split_digits(bank.tapq)
+    off = (15 - ks) // 2
+    frame = np.zeros((nf, 4, 16, 16), np.int8)           # part order: re_lo, re_hi, im_lo, im_hi
+    for part, (dig, ri) in enumerate([(lo, 0), (hi, 0), (lo, 1), (hi, 1)]):
+        frame[:, part, off:off + ks, off:off + ks] = dig[:, ri]
+    mt_n = (nf + 7) // 8
+    pk = packed.reshape(mt_n, 8, 64, 16)
+    for mt in range(mt_n):
+        for kk in range(8):
+            for lane in (0, 1, 5, 31, 32, 47, 63):
+                r, h = lane & 31, lane >> 5
+                f, part = 8 * mt + r // 4, r & 3
+                want = frame[f, part, 2 * kk + h] if f < nf else np.zeros(16, np.int8)
+                assert np.array_equal(pk[mt, kk, lane], want)
+    assert np.array_equal(bias[:nf], 128 * bank.tapq[:, 0].astype(np.int64).sum(axis=(1, 2)))
+    assert np.all(bias[nf:] == 0)
+
+
+def test_bank_pack_rejects_bad_input(lib):
+    bank = make_bank()
+    tq = np.ascontiguousarray(bank.tapq)
+    packed = np.zeros(lib.gcs_bank_packed_bytes(24), np.int8)
+    bias = np.zeros(24, np.int32)
+    assert lib.gcs_bank_pack(None, 24, 15, packed.ctypes.data, bias.ctypes.data) == 1
+    assert lib.gcs_bank_pack(tq.ctypes.data, 0, 15, packed.ctypes.data, bias.ctypes.data) == 1
+    assert lib.gcs_bank_pack(tq.ctypes.data, 24, 16, packed.ctypes.data, bias.ctypes.data) == 1
+    assert b"ksize" in lib.gcs_last_error()
+    bad = tq.copy()
+    bad[0, 1, 0, 0] += 1                                  # imaginary part no longer sums to zero
+    assert lib.gcs_bank_pack(bad.ctypes.data, 24, 15, packed.ctypes.data, bias.ctypes.data) == 1
+
+
+def test_device_entry_points_validate_before_launching(lib):
+    """Argument errors are reported without touching the GPU (so this runs on the CPU box)."""
+    one = C.c_void_p(16)                                   # non-NULL dummy, never dereferenced
+    assert lib.gcs_gabor_features(None, 1, 16, 16, one, one, 24, 11, one, None) == 1
+    assert lib.gcs_gabor_features(one, 1, 7, 16, one, one, 24, 11, one, None) == 1      # H < 8
+    assert lib.gcs_gabor_features(one, 0, 16, 16, one, one, 24, 11, one, None) == 1
+    assert lib.gcs_kmeans_init(one, 2, 16, 16, 72, 17, 2, one, None) == 1             # k > 16
+    assert lib.gcs_kmeans_init(one, 4, 16, 16, 72, 8, 3, one, None) == 1              # n_sets not in {1,B}
+    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 72, 0, 1, one, one, None) == 1
+    assert lib.gcs_kmeans_reduce(None, 1, 16, 16, 72, 8, 1, one, None) == 1
+    assert lib.gcs_kmeans_finalize(one, 0, 8, 72, one, None) == 1
+    assert lib.gcs_labels_widen(one, 1, 0, 16, one, None) == 1
+    assert lib.gcs_features_unpack(one, 1, 16, 16, 0, one, None) == 1
+    assert len(lib.gcs_last_error()) > 0
+
+
+def test_product_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gabor_color_image_segmentation_amd import segment, GcsError
+    with pytest.raises(GcsError):
+        segment(np.zeros((16, 16, 3), np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gabor_color_image_segmentation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "spec_oracle" not in src and "c_oracle" not in src, f

@@ -1,0 +1,84 @@
+"""The scoring mirror against numbers produced by the reference's own metrics class
+(tests/golden/make_scoring_golden.py ran /root/reference/BSD_metrics/metrics.py)."""
+import json
+import os
+import numpy as np
+import pytest
+
+from gabor_color_image_segmentation_amd.evaluate import metrics, boundary_scores, find_boundaries
+from oracle import spec_oracle as so
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INP = np.load(os.path.join(GOLD, "bsd_inputs.npz"))
+PATH = np.load(os.path.join(GOLD, "path_golden.npz"))
+MAPS = np.load(os.path.join(GOLD, "scoring_maps.npz"))
+SCORES = json.load(open(os.path.join(GOLD, "scoring_golden.json")))
+
+
+def _segs(i):
+    return [INP["seg_%s_%d" % (i, a)] for a in range(int(INP["nseg_" + i]))]
+
+
+def _label_map(i, name):
+    h, w = INP["img_" + i].shape[:2]
+    if name == "oracle":
+        return PATH["labels_" + i].astype(np.int32)
+    if name == "halves":
+        return (np.arange(w)[None, :] >= w // 2).astype(np.int32) * np.ones((h, 1), np.int32)
+    if name == "blocks":
+        return ((np.arange(h)[:, None] // 16) * ((w + 15) // 16) + np.arange(w)[None, :] // 16).astype(np.int32)
+    return MAPS["slic_" + i].astype(np.int32)
+
+
+@pytest.mark.parametrize("key", sorted(SCORES))
+def test_all_metrics_equal_the_reference(key):
+    i, name = key.split("/")
+    m = metrics(INP["img_" + i], _label_map(i, name), _segs(i))
+    m.set_metrics()
+    got, ref = m.get_metrics(), SCORES[key]
+    assert got["regions"] == ref["regions"]
+    for k in ("recall", "precision", "density"):
+        assert got[k] == ref[k], k                     # same integer counts, same float divisions
+    for k in ("underseg", "undersegNP", "compactness"):
+        assert got[k] == pytest.approx(ref[k], rel=1e-12), k
+    p, r = ref["precision"], ref["recall"]
+    assert got["fmeasure"] == pytest.approx(2 * p * r / (p + r), rel=1e-15)
+
+
+def test_boundary_scores_match_oracle_restatement():
+    i = "100080"
+    lab = _label_map(i, "oracle")
+    s = boundary_scores(lab, _segs(i))
+    r, p = so.boundary_recall_precision(lab, _segs(i))
+    assert s["recall"] == r and s["precision"] == p and s["fmeasure"] == so.fmeasure(r, p)
+
+
+def test_label_permutation_does_not_change_boundary_scores():
+    i = "100075"
+    lab = _label_map(i, "oracle")
+    perm = np.array([3, 7, 1, 0, 6, 2, 5, 4])
+    assert boundary_scores(lab, _segs(i)) == boundary_scores(perm[lab], _segs(i))
+
+
+def test_constant_label_map_divides_by_zero_like_the_reference():
+    """metrics.py:94 divides by the number of boundary pixels: a one-label map raises."""
+    i = "100075"
+    h, w = INP["img_" + i].shape[:2]
+    m = metrics(None, np.zeros((h, w), np.int32), _segs(i))
+    m.set_boundary_recall()
+    assert m.recall == 0.0
+    with pytest.raises(ZeroDivisionError):
+        m.set_boundary_precision()
+
+
+def test_empty_truth_list_divides_by_zero_like_the_reference():
+    m = metrics(None, np.zeros((8, 8), np.int32), [])
+    with pytest.raises(ZeroDivisionError):
+        m.set_boundary_recall()                        # metrics.py:74
+
+
+def test_find_boundaries_is_thick_and_ignores_the_image_border():
+    lab = np.zeros((6, 6), np.int32)
+    lab[:, 3:] = 1
+    b = find_boundaries(lab)
+    assert b[:, 2].all() and b[:, 3].all() and b.sum() == 12

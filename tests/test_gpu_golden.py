@@ -1,0 +1,123 @@
+"""GPU at full BSD size: committed goldens, the reference-pinned scoring, and size-independent
+properties at BASELINE.json's batch shape."""
+import json
+import os
+import numpy as np
+import pytest
+
+from oracle import spec_oracle as so, c_oracle as co
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def seg(built):
+    import torch
+    assert torch.cuda.is_available()
+    from gabor_color_image_segmentation_amd import Segmenter
+    return Segmenter()
+
+
+@pytest.fixture(scope="module")
+def fixtures():
+    return np.load(os.path.join(GOLD, "bsd_inputs.npz")), np.load(os.path.join(GOLD, "path_golden.npz"))
+
+
+def test_bsd_images_labels_centroid_free_parity(seg, fixtures):
+    """Both orientations ((321,481) and (481,321)), default bank/k/n_iter: bit-identical label maps."""
+    inp, gold = fixtures
+    for i in inp["ids"]:
+        lab = seg(inp["img_" + str(i)])
+        assert lab.dtype == np.int32 and lab.shape == inp["img_" + str(i)].shape[:2]
+        assert np.array_equal(lab, gold["labels_" + str(i)]), f"{i}: {(lab != gold['labels_' + str(i)]).mean():.3%}"
+
+
+def test_bsd_images_feature_goldens(seg, fixtures):
+    import torch
+    inp, gold = fixtures
+    for i in inp["ids"][:2]:
+        img = inp["img_" + str(i)]
+        f = seg.features_device(torch.from_numpy(img[None]).cuda()).cpu().numpy().view(np.uint16)[0]
+        assert np.array_equal(f.reshape(72, -1).astype(np.int64).sum(axis=1), gold["feat_sum_" + str(i)])
+        assert np.array_equal(f.reshape(72, -1).max(axis=1), gold["feat_max_" + str(i)])
+        for (y, x), pf in zip(gold["probe_yx_" + str(i)], gold["probe_feat_" + str(i)]):
+            assert np.array_equal(f[:, y, x], pf)
+
+
+def test_bsd_boundary_f_measure_identical_to_reference_scoring(seg, fixtures):
+    """P / R from the reference's own metrics class on the oracle's label map
+    (scoring_golden.json) == P / R of the GPU label map through the scoring mirror."""
+    from gabor_color_image_segmentation_amd.evaluate import boundary_scores
+    inp, _ = fixtures
+    scores = json.load(open(os.path.join(GOLD, "scoring_golden.json")))
+    for i in inp["ids"]:
+        i = str(i)
+        segs = [inp["seg_%s_%d" % (i, a)] for a in range(int(inp["nseg_" + i]))]
+        s = boundary_scores(seg(inp["img_" + i]), segs)
+        ref = scores[i + "/oracle"]
+        assert s["recall"] == ref["recall"] and s["precision"] == ref["precision"]
+        assert s["fmeasure"] == 2 * ref["precision"] * ref["recall"] / (ref["precision"] + ref["recall"])
+
+
+def test_full_size_batch_vs_c_oracle_and_properties(seg):
+    """Batch of 6 synthetic 481x321 images: two checked pixel-for-pixel against the C oracle, all
+    against batch/single consistency, label range and determinism."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(6, 321, 481, seed=0)
+    out = seg.segment_batch(imgs)
+    assert out.shape == (6, 321, 481) and out.min() >= 0 and out.max() <= 7
+    ref = co.segment_batch(imgs[[0, 5]], seg.bank.tapq, seg.bank.shift)
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[5], ref[1])
+    assert np.array_equal(seg(imgs[3]), out[3])                      # segment == segment_batch row
+    assert np.array_equal(seg.segment_batch(imgs), out)              # deterministic
+    assert np.array_equal(seg.segment_batch(imgs[::-1])[::-1], out)  # per-image: order independent
+
+
+def test_global_codebook_full_size_vs_c_oracle(seg):
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(3, 321, 481, seed=9)
+    got = seg.segment_batch(imgs, mode="global")
+    assert np.array_equal(got, co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, mode="global"))
+
+
+def test_k16_two_mfma_tiles_and_portrait(built):
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(2, 481, 321, seed=4)
+    s = Segmenter(k=16, n_iter=4)
+    got = s.segment_batch(imgs)
+    ref = co.segment_batch(imgs, s.bank.tapq, s.bank.shift, k=16, n_iter=4)
+    assert np.array_equal(got, ref)
+
+
+def test_wide_feature_vectors_use_the_generic_pass(built):
+    """D = 81 >= 80 planes: the non-MFMA k-means pass; still bit-exact."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(2, 40, 56, seed=6)
+    s = Segmenter(n_scales=3, n_orient=9, k=4, n_iter=3)
+    assert s.bank.n_features == 81
+    got = s.segment_batch(imgs)
+    for b in range(2):
+        assert np.array_equal(got[b], so.segment(imgs[b], n_scales=3, n_orient=9, k=4, n_iter=3))
+
+
+def test_sixty_four_filter_bank_features(built):
+    """BASELINE config 4's 8x8 bank (F = 64, D = 192): three MFMA row-tile launches."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(1, 48, 72, seed=12)
+    s = Segmenter(n_scales=8, n_orient=8)
+    got = s.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)[0]
+    tapq, shift = so.bank(8, 8)
+    assert np.array_equal(got, co.gabor_features(imgs[0], tapq, shift))
+
+
+def test_degenerate_inputs(seg):
+    """Constant image: every feature equal, all pixels tie -> label 0 everywhere (lowest index)."""
+    img = np.full((32, 48, 3), 77, np.uint8)
+    assert np.array_equal(seg(img), np.zeros((32, 48), np.int32))
+    with pytest.raises(ValueError):
+        seg(np.zeros((7, 40, 3), np.uint8))

@@ -1,0 +1,61 @@
+"""Host orchestration (grouping, Lloyd schedule, argument checks) with the CPU fake backend."""
+import numpy as np
+import pytest
+import torch
+
+from gabor_color_image_segmentation_amd import Segmenter, make_bank
+from gabor_color_image_segmentation_amd.synthetic import synthetic_batch, synthetic_shard
+from oracle import spec_oracle as so
+from fake_ops import OracleOps
+
+
+def _seg(**kw):
+    bank_kw = {a: kw[a] for a in ("n_scales", "n_orient", "ksize") if a in kw}
+    return Segmenter(ops=OracleOps(make_bank(**bank_kw)), **kw)
+
+
+def test_per_image_groups_equal_the_oracle():
+    imgs = synthetic_batch(5, 24, 40, seed=1)
+    seg = _seg(n_iter=3)
+    out = seg.segment_device(torch.from_numpy(imgs), mode="per_image", group=2).numpy()
+    assert [c for c in seg.ops.calls if c[0] == "gabor"] == [("gabor", 2), ("gabor", 2), ("gabor", 1)]
+    for b in range(5):
+        assert np.array_equal(out[b], so.segment(imgs[b], n_iter=3))
+
+
+def test_global_mode_equals_the_oracle():
+    imgs = synthetic_batch(3, 24, 40, seed=2)
+    out = _seg(n_iter=4, k=5).segment_device(torch.from_numpy(imgs), mode="global").numpy()
+    assert np.array_equal(out, so.segment_batch(imgs, mode="global", k=5, n_iter=4))
+
+
+def test_n_iter_one_returns_the_init_assignment():
+    imgs = synthetic_batch(1, 16, 24, seed=3)
+    out = _seg(n_iter=1).segment_device(torch.from_numpy(imgs)).numpy()
+    assert np.array_equal(out[0], so.segment(imgs[0], n_iter=1))
+
+
+def test_argument_checks():
+    seg = _seg()
+    with pytest.raises(ValueError):
+        seg.segment_device(torch.zeros((1, 16, 16, 3), dtype=torch.float32))
+    with pytest.raises(ValueError):
+        seg.segment_device(torch.zeros((16, 16, 3), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        seg.segment_device(torch.zeros((1, 7, 16, 3), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        seg.segment_device(torch.zeros((1, 16, 16, 3), dtype=torch.uint8), mode="batch")
+    with pytest.raises(ValueError):
+        seg(np.zeros((16, 16), np.uint8))
+    with pytest.raises(ValueError):
+        seg(np.zeros((16, 16, 3), np.float32))
+    with pytest.raises(ValueError):
+        Segmenter(k=17, ops=object())
+    with pytest.raises(ValueError):
+        Segmenter(n_iter=0, ops=object())
+
+
+def test_synthetic_shards_tile_the_global_batch():
+    full = synthetic_batch(5, 16, 24, seed=7)
+    assert np.array_equal(np.concatenate([synthetic_shard(0, 2, 16, 24, seed=7), synthetic_shard(2, 3, 16, 24, seed=7)]), full)
+    assert full.dtype == np.uint8 and len({im.tobytes() for im in full}) == 5
