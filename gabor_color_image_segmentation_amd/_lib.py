@@ -10,9 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgcs.so")
+LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -29,7 +29,8 @@ SIGNATURES = {
     "gcs_label_slab_bytes": (_sz, [_i, _i, _i]),
     "gcs_kmeans_parts_per_image": (_sz, [_i, _i]),
     "gcs_kmeans_partial_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "gcs_gabor_workspace_bytes": (_sz, [_i, _i, _i]),
+    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gcs_features_unpack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

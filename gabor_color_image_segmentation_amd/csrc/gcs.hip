@@ -125,7 +125,7 @@ constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
 constexpr int G_HALO = 7;
 constexpr int G_LROWS = G_TH + 15;  // 47 rows: halo 14 + the zero-tap row 15
 constexpr int G_LPITCH = 96;        // bytes per LDS tile row (>= 64 + 16 + 12)
-constexpr int G_LCOLS = G_TW + 15;  // 79 columns carry image data
+
 
 __device__ __forceinline__ int reflect_clamp(int i, int n) {
     if (i < 0) i = -1 - i;
@@ -143,13 +143,42 @@ __device__ __forceinline__ unsigned isqrt31(unsigned n) {
     return q;
 }
 
+// Pre-pass: interleaved uint8 RGB -> planar (pixel - 128) int8 with the reflect border and
+// the tile over-read already materialised: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128
+// for r < tiles_y*32 + 15, u < tiles_x*64 + 32. The main kernel then stages tiles with aligned
+// 16-byte copies and no index arithmetic. ~26 B of extra HBM traffic per pixel-channel row: noise.
+__global__ __launch_bounds__(256) void gabor_pad_kernel(const uint8_t *__restrict__ img, int H, int W, int Hp,
+                                                        int Wp, int8_t *__restrict__ planes) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int gy = reflect_clamp(r - G_HALO, H);
+    const uint8_t *row = img + ((size_t)b * H + gy) * W * 3;
+    for (int u4 = blockIdx.x * blockDim.x + threadIdx.x; u4 < Wp / 4; u4 += gridDim.x * blockDim.x) {
+        unsigned o[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gx = reflect_clamp(4 * u4 + e - G_HALO, W);
+            const uint8_t *p = row + (size_t)gx * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] |= (unsigned)(p[c] ^ 0x80) << (8 * e);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
+    }
+}
+
+#ifndef GCS_GABOR_WAVES
+#define GCS_GABOR_WAVES 2
+#endif
+#ifndef GCS_GABOR_MTMAX
+#define GCS_GABOR_MTMAX 2
+#endif
 template <int MT>
-__global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
-    const uint8_t *__restrict__ img, int H, int W, const int8_t *__restrict__ apack,
-    const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats,
-    int pitch, int tiles_x) {
+__global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
+    const int8_t *__restrict__ planes, int H, int Hp, int Wp, const int8_t *__restrict__ apack,
+    const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats, int pitch,
+    int tiles_x) {
     __shared__ __attribute__((aligned(16))) int8_t s_tile[3][G_LROWS][G_LPITCH];
-    __shared__ __attribute__((aligned(16))) int8_t s_a[MT * 8 * 64 * 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,33 +188,28 @@ __global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
     const int y0 = ty * G_TH, x0 = tx * G_TW;
     const int D = 3 * F;
 
-    // ---- stage: A fragments (16 B per lane, lane-linear) and the 3-channel image tile
-    {
-        const v4i *src = reinterpret_cast<const v4i *>(apack + (size_t)mt0 * 8 * 64 * 16);
-        v4i *dst = reinterpret_cast<v4i *>(s_a);
-        for (int i = tid; i < MT * 8 * 64; i += 256) dst[i] = src[i];
-        const uint8_t *ib = img + (size_t)b * H * W * 3;
-        for (int i = tid; i < G_LROWS * G_LPITCH; i += 256) {
-            const int row = i / G_LPITCH, col = i % G_LPITCH;
-            int8_t v0 = 0, v1 = 0, v2 = 0;
-            if (col < G_LCOLS) {
-                const int gy = reflect_clamp(y0 - G_HALO + row, H);
-                const int gx = reflect_clamp(x0 - G_HALO + col, W);
-                const uint8_t *p = ib + ((size_t)gy * W + gx) * 3;
-                v0 = (int8_t)(p[0] ^ 0x80);
-                v1 = (int8_t)(p[1] ^ 0x80);
-                v2 = (int8_t)(p[2] ^ 0x80);
-            }
-            s_tile[0][row][col] = v0;
-            s_tile[1][row][col] = v1;
-            s_tile[2][row][col] = v2;
-        }
+    // ---- stage the 3-channel tile: 3 x 47 rows x 6 aligned 16-byte chunks
+    for (int i = tid; i < 3 * G_LROWS * (G_LPITCH / 16); i += 256) {
+        const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
+        const int row = rc % G_LROWS, c = rc / G_LROWS;
+        const v4i v = *reinterpret_cast<const v4i *>(planes + (((size_t)b * 3 + c) * Hp + y0 + row) * Wp + x0 +
+                                                     16 * ch16);
+        *reinterpret_cast<v4i *>(&s_tile[c][row][16 * ch16]) = v;
     }
+    // ---- the whole A operand lives in registers: MT x 8 lane-linear 16-byte fragments
+    v4i afr[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            afr[mt][kk] = reinterpret_cast<const v4i *>(apack)[((size_t)(mt0 + mt) * 8 + kk) * 64 + lane];
     __syncthreads();
 
+    // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
+    // for a pixel shift s = 4*qq + t in 0..7. A lane therefore ends up owning 8 consecutive
+    // pixels (16 bytes) per filter and a store instruction writes whole 128-byte lines.
     const int r = lane & 31, h = lane >> 5;
-    const int li = r & 3, lyy = r >> 2;
-    const int oy = y0 + wave * 8 + lyy; // this lane's output row
+    const int li = r & 7, lyy = r >> 3;
     if (y0 + wave * 8 >= H) return;     // whole wave outside the image (no barrier follows)
 
     int bias_v[MT][4];
@@ -194,66 +218,86 @@ __global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias_v[mt][g] = bias[8 * (mt0 + mt) + 2 * g + h];
 
-
     for (int c = 0; c < 3; ++c) {
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 16*li + 4*q
-            int win[8][5];
+        for (int rb = 0; rb < 2; ++rb) {       // two 4-row blocks per wave
+            const int trow = wave * 8 + rb * 4 + lyy;
+            unsigned outp[MT][4][4];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int *rp = reinterpret_cast<const int *>(
-                    &s_tile[c][wave * 8 + lyy + 2 * kk + h][16 * li + 4 * q]);
+            for (int qq = 0; qq < 2; ++qq) {
+                // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 8*li + 4*qq
+                int win[8][5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
-            }
-            unsigned outp[MT][4][2];
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int *rp = reinterpret_cast<const int *>(&s_tile[c][trow + 2 * kk + h][8 * li + 4 * qq]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // B fragments of pixel shift s = 4q + t: bytes [t, t+16) of each 20-byte window
-                v4i bf[8];
+                    for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
+                }
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
+                for (int t = 0; t < 4; ++t) {
+                    v16i acc[MT];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        bf[kk][j] = (t == 0) ? win[kk][j]
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[mt][e] = 0;   // inline-constant C of the first MFMA
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
+                        v4i bf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            bf[j] = (t == 0) ? win[kk][j]
                                              : (int)__builtin_amdgcn_alignbyte((unsigned)win[kk][j + 1],
                                                                                (unsigned)win[kk][j], t);
+#ifdef GCS_ABL_NOMFMA
+                        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] += bf[0] + afr[mt][kk][0]; acc[mt][5] += bf[1]; acc[mt][10] += bf[2] ^ afr[mt][kk][1]; acc[mt][15] += bf[3]; }
+#else
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    // opaque copy: keeps the (loop-invariant) A-fragment LDS reads here instead
-                    // of hoisted out of every loop into 96 VGPRs
-                    unsigned aoff = (unsigned)(mt * 8 * 64 + lane) * 16u;
-                    asm volatile("" : "+v"(aoff));
-                    const v4i *ap = reinterpret_cast<const v4i *>(s_a + aoff);
-                    v16i acc;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = ((e & 3) == 0) ? bias_v[mt][e >> 2] : 0;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk)
-                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ap[kk * 64], bf[kk], acc, 0, 0, 0);
-                    // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int a_re = ((acc[4 * g + 1] << 8) + acc[4 * g + 0]) >> shift;
-                        const int a_im = ((acc[4 * g + 3] << 8) + acc[4 * g + 2]) >> shift;
-                        const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
-                        const unsigned m = isqrt31(n);
-                        if ((t & 1) == 0)
-                            outp[mt][g][t >> 1] = m;
-                        else
-                            outp[mt][g][t >> 1] |= m << 16;
-                        // materialise now: otherwise hipcc sinks the whole epilogue into the
-                        // store branches and keeps every accumulator live until then
-                        asm volatile("" : "+v"(outp[mt][g][t >> 1]));
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
+#endif
                     }
+                    // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter.
+                    // All 4*MT magnitudes are computed as independent chains (ILP), then pinned.
+                    unsigned mag[MT][4];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int a_re = ((acc[mt][4 * g + 1] << 8) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
+                            const int a_im = ((acc[mt][4 * g + 3] << 8) + acc[mt][4 * g + 2]) >> shift;
+                            const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+#ifdef GCS_ABL_NOEPI
+                            mag[mt][g] = (unsigned)(acc[mt][4 * g] ^ acc[mt][4 * g + 1] ^ acc[mt][4 * g + 2] ^ acc[mt][4 * g + 3]) & 0xffffu; (void)n;
+#else
+                            mag[mt][g] = isqrt31(n);
+#endif
+                        }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            unsigned &o = outp[mt][g][2 * qq + (t >> 1)];
+                            if ((t & 1) == 0)
+                                o = mag[mt][g];
+                            else
+                                o |= mag[mt][g] << 16;
+                            // materialise now: otherwise hipcc sinks the whole epilogue into the
+                            // store branches and keeps every accumulator live until then
+                            asm volatile("" : "+v"(o));
+                        }
+                    // keep hipcc from building all four shifts' fragments up front
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // keep hipcc from building all four shifts' fragments up front (128 VGPRs)
-                __builtin_amdgcn_sched_barrier(0);
             }
-            // 4 consecutive pixels x = x0 + 16*li + 4*q .. +3 of row oy: one 8-byte store per filter
-            const int ox = x0 + 16 * li + 4 * q;
+            // 8 consecutive pixels x = x0 + 8*li .. +7 of row oy: one 16-byte store per filter;
+            // the 8 li-lanes of a row cover 128 contiguous bytes
+            const int oy = y0 + trow, ox = x0 + 8 * li;
+#ifdef GCS_ABL_NOSTORE
+            if (oy < H && ox < pitch && shift == 77) {
+#else
             if (oy < H && ox < pitch) {
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -262,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
                         if (f < F) {
                             uint16_t *dst =
                                 feats + (((size_t)b * D + (size_t)c * F + f) * H + oy) * pitch + ox;
-                            *reinterpret_cast<uint2 *>(dst) = make_uint2(outp[mt][g][0], outp[mt][g][1]);
+                            *reinterpret_cast<uint4 *>(dst) =
+                                make_uint4(outp[mt][g][0], outp[mt][g][1], outp[mt][g][2], outp[mt][g][3]);
                         }
                     }
             }
@@ -270,28 +315,43 @@ __global__ __launch_bounds__(256, 2) void gabor_mfma_kernel(
     }
 }
 
+static inline int gabor_hp(int H) { return (H + G_TH - 1) / G_TH * G_TH + 15; }
+static inline int gabor_wp(int W) { return (W + G_TW - 1) / G_TW * G_TW + 32; }
+
+extern "C" size_t gcs_gabor_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * 3 * gabor_hp(H) * gabor_wp(W);
+}
+
 extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const int8_t *packed,
-                                  const int32_t *bias, int F, int shift, uint16_t *feats,
+                                  const int32_t *bias, int F, int shift, void *workspace, uint16_t *feats,
                                   gcs_stream_t stream) {
-    if (!img || !packed || !bias || !feats) return fail(GCS_EINVAL, "gcs_gabor_features: NULL pointer");
+    if (!img || !packed || !bias || !feats || !workspace)
+        return fail(GCS_EINVAL, "gcs_gabor_features: NULL pointer");
     if (B <= 0 || F <= 0) return fail(GCS_EINVAL, "gcs_gabor_features: B and n_filters must be > 0");
     if (H < 8 || W < 8) return fail(GCS_EINVAL, "gcs_gabor_features: H and W must be >= 8");
     if (shift < 0 || shift > 23) return fail(GCS_EINVAL, "gcs_gabor_features: shift out of range");
     if (B > 65535) return fail(GCS_EINVAL, "gcs_gabor_features: B too large for one launch");
     const int pitch = (int)gcs_feature_pitch(W);
     const int tiles_x = (W + G_TW - 1) / G_TW, tiles_y = (H + G_TH - 1) / G_TH;
+    const int Hp = gabor_hp(H), Wp = gabor_wp(W);
+    if (Hp > 65535) return fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
+    int8_t *planes = static_cast<int8_t *>(workspace);
+    hipLaunchKernelGGL(gabor_pad_kernel, dim3((Wp / 4 + 255) / 256, Hp, B), dim3(256), 0, stream, img, H, W, Hp, Wp,
+                       planes);
+    GCS_CHECK_LAUNCH("gcs_gabor_features(pad)");
     const dim3 grid(tiles_x * tiles_y, B), block(256);
     const int MT = mtiles(F);
-    for (int mt0 = 0; mt0 < MT; mt0 += 3) {
-        const int n = MT - mt0 >= 3 ? 3 : MT - mt0;
+    for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
+        const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
         if (n == 3)
-            hipLaunchKernelGGL(gabor_mfma_kernel<3>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+            hipLaunchKernelGGL(gabor_mfma_kernel<3>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
                                F, shift, feats, pitch, tiles_x);
         else if (n == 2)
-            hipLaunchKernelGGL(gabor_mfma_kernel<2>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+            hipLaunchKernelGGL(gabor_mfma_kernel<2>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
                                F, shift, feats, pitch, tiles_x);
         else
-            hipLaunchKernelGGL(gabor_mfma_kernel<1>, grid, block, 0, stream, img, H, W, packed, bias, mt0,
+            hipLaunchKernelGGL(gabor_mfma_kernel<1>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
                                F, shift, feats, pitch, tiles_x);
         GCS_CHECK_LAUNCH("gcs_gabor_features");
     }

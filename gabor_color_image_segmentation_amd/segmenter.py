@@ -46,6 +46,7 @@ class HipOps:
                                           bias.ctypes.data), "gcs_bank_pack")
         self.packed = torch.from_numpy(packed).to(self.device)
         self.bias = torch.from_numpy(bias).to(self.device)
+        self._gabor_ws = None
 
     # ---- allocation helpers (bytes buffers; layouts are opaque, see gcs.h)
     def empty_bytes(self, n):
@@ -66,9 +67,13 @@ class HipOps:
     # ---- device entry points
     def gabor_features(self, imgs, feats):
         b, h, w, _ = imgs.shape
+        need = self.lib.gcs_gabor_workspace_bytes(b, h, w)
+        if self._gabor_ws is None or self._gabor_ws.numel() < need:
+            self._gabor_ws = self.empty_bytes(need)
         _lib.check(self.lib.gcs_gabor_features(imgs.data_ptr(), b, h, w, self.packed.data_ptr(),
                                                self.bias.data_ptr(), self.bank.n_filters,
-                                               self.bank.shift, feats.data_ptr(), self._stream()),
+                                               self.bank.shift, self._gabor_ws.data_ptr(),
+                                               feats.data_ptr(), self._stream()),
                    "gcs_gabor_features")
 
     def features_unpack(self, feats, b, h, w):

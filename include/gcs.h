@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 1
+#define GCS_ABI_VERSION 2
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -61,11 +61,15 @@ size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 
 /* ---- device entry points ---------------------------------------------------------------- */
 
+/* Scratch for gcs_gabor_features: the reflect-padded planar (pixel-128) image. */
+size_t gcs_gabor_workspace_bytes(int B, int H, int W);
+
 /* SPEC.md §3: img_dev [B][H][W][3] uint8 -> feats_dev slab, D = 3*F, d = c*F + f.
- * Fills the slot's first stage (script.py:30). Requires H, W >= 8. */
+ * Fills the slot's first stage (script.py:30). Requires H, W >= 8. workspace_dev:
+ * gcs_gabor_workspace_bytes() bytes of device scratch, contents undefined before and after. */
 int gcs_gabor_features(const uint8_t *img_dev, int B, int H, int W, const int8_t *packed_dev,
-                       const int32_t *bias_dev, int n_filters, int shift, uint16_t *feats_dev,
-                       gcs_stream_t stream);
+                       const int32_t *bias_dev, int n_filters, int shift, void *workspace_dev,
+                       uint16_t *feats_dev, gcs_stream_t stream);
 
 /* Slab -> canonical [B][D][H][W] uint16 (tests / debugging). */
 int gcs_features_unpack(const uint16_t *feats_dev, int B, int H, int W, int D, uint16_t *out_dev,
