@@ -160,7 +160,7 @@ def main():
                                   gbs=round(g_bytes / g_ms / 1e6, 1), tops=round(g_ops / g_ms / 1e9, 1),
                                   hbm_frac=round(g_bytes / g_ms / 1e6 / HBM_PEAK_GBS, 4),
                                   mfma_frac=round(g_ops / g_ms / 1e9 / I8_MFMA_PEAK_TOPS, 4)),
-        "kmeans_assign_kernel": dict(launches=a_n, avg_ms=round(a_ms, 4), alg_bytes=a_bytes,
+        "kmeans_pass_mfma_kernel": dict(launches=a_n, avg_ms=round(a_ms, 4), alg_bytes=a_bytes,
                                      gbs=round(a_bytes / a_ms / 1e6, 1),
                                      hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4)),
     }
@@ -172,8 +172,8 @@ def main():
                         unit="TFLOP/s", frac=kg["mfma_frac"], traffic=None, ops="int8 MAC x2 (TOP/s)",
                         hbm_gbs=kg["gbs"], hbm_frac=kg["hbm_frac"])
     else:
-        ka = kernels["kmeans_assign_kernel"]
-        roofline = dict(kernel="kmeans_assign_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
+        ka = kernels["kmeans_pass_mfma_kernel"]
+        roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ka["hbm_frac"], traffic=None)
 
     extra = {}

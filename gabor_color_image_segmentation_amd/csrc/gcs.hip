@@ -48,27 +48,41 @@ static inline int mtiles(int F) { return (F + 7) / 8; }
 extern "C" size_t gcs_bank_packed_bytes(int F) { return F > 0 ? (size_t)mtiles(F) * 8 * 64 * 16 : 0; }
 extern "C" size_t gcs_bank_bias_count(int F) { return F > 0 ? (size_t)mtiles(F) * 8 : 0; }
 extern "C" size_t gcs_feature_pitch(int W) { return W > 0 ? (size_t)round_up(W, 8) : 0; }
+// Pixels per feature plane / label plane: H*pitch rounded up to the k-means tile (256 px), so
+// a tile never crosses a plane boundary and staging needs no bounds checks.
+extern "C" size_t gcs_feature_plane_stride(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    return ((size_t)H * gcs_feature_pitch(W) + 255) / 256 * 256;
+}
 extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int D) {
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
-    return (size_t)B * D * H * gcs_feature_pitch(W) * sizeof(uint16_t);
+    return (size_t)B * D * gcs_feature_plane_stride(H, W) * sizeof(uint16_t);
 }
 extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * H * gcs_feature_pitch(W);
+    return (size_t)B * gcs_feature_plane_stride(H, W);
 }
-// Workgroups (= partial-sum rows) per image of the assign pass. Bounded so that one
-// workgroup's uint32 LDS accumulators cannot overflow (<= 65536 pixels x 46341).
-extern "C" size_t gcs_kmeans_parts_per_image(int H, int W) {
-    if (H <= 0 || W <= 0) return 0;
-    size_t px = (size_t)H * gcs_feature_pitch(W);
-    size_t need = (px + 65535) / 65536;
-    size_t want = (px + 8191) / 8192; // ~8K pixels per workgroup
-    if (want > 16) want = 16;
-    return need > want ? need : (want ? want : 1);
+// Workgroups (= partial-sum rows) per image of one Lloyd pass. Sized to the machine: the pass
+// kernel runs 3 workgroups per CU, so B*parts aims at one full wave of 256*3 workgroups (a
+// second, partly filled wave of workgroups would idle most of the chip). Lower bound: one
+// workgroup's int32 accumulators must not overflow (<= 65536 pixels); upper bound: at least
+// 8 tiles per workgroup to amortise its prologue.
+#ifndef GCS_KP_SLOTS
+#define GCS_KP_SLOTS 768
+#endif
+extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t px = gcs_feature_plane_stride(H, W);
+    const size_t need = (px + 65535) / 65536;
+    size_t most = px / 256 / 8;
+    if (most < 1) most = 1;
+    size_t want = (GCS_KP_SLOTS + (size_t)B - 1) / (size_t)B;
+    if (want > most) want = most;
+    return need > want ? need : want;
 }
 extern "C" size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k) {
     if (B <= 0 || D <= 0 || k <= 0) return 0;
-    return (size_t)B * gcs_kmeans_parts_per_image(H, W) * k * (D + 1) * sizeof(uint64_t);
+    return (size_t)B * gcs_kmeans_parts_per_image(B, H, W) * k * (D + 1) * sizeof(uint64_t);
 }
 
 // ------------------------------------------------------------------------ bank pack (host)
@@ -117,6 +131,13 @@ extern "C" int gcs_bank_pack(const int16_t *tapq, int F, int ks, int8_t *packed,
                 }
             }
     return GCS_OK;
+}
+
+// Feature slab addressing (tile-major): [B][tile][D][256 px] uint16, tile = flat pixel index
+// pp = y*pitch + x divided by 256. One k-means tile (all D planes of 256 pixels) is a single
+// contiguous D*512-byte run; 8-pixel (16-byte) groups never straddle a tile.
+__device__ __forceinline__ size_t slab_index(size_t image_tile0, int D, int d, int pp) {
+    return ((image_tile0 + (size_t)(pp >> 8)) * D + d) * 256 + (pp & 255);
 }
 
 // ================================================================================ Gabor
@@ -177,7 +198,7 @@ template <int MT>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int H, int Hp, int Wp, const int8_t *__restrict__ apack,
     const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats, int pitch,
-    int tiles_x) {
+    size_t pstride, int tiles_x) {
     __shared__ __attribute__((aligned(16))) int8_t s_tile[3][G_LROWS][G_LPITCH];
 
     const int tid = threadIdx.x;
@@ -304,10 +325,12 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     for (int g = 0; g < 4; ++g) {
                         const int f = 8 * (mt0 + mt) + 2 * g + h;
                         if (f < F) {
-                            uint16_t *dst =
-                                feats + (((size_t)b * D + (size_t)c * F + f) * H + oy) * pitch + ox;
+                            // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
+                            // signed MFMA digits for the k-means pass, which stages them untouched
+                            uint16_t *dst = feats + slab_index((size_t)b * (pstride >> 8), D, c * F + f, oy * pitch + ox);
                             *reinterpret_cast<uint4 *>(dst) =
-                                make_uint4(outp[mt][g][0], outp[mt][g][1], outp[mt][g][2], outp[mt][g][3]);
+                                make_uint4(outp[mt][g][0] ^ 0x80808080u, outp[mt][g][1] ^ 0x80808080u,
+                                           outp[mt][g][2] ^ 0x80808080u, outp[mt][g][3] ^ 0x80808080u);
                         }
                     }
             }
@@ -333,6 +356,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     if (shift < 0 || shift > 23) return fail(GCS_EINVAL, "gcs_gabor_features: shift out of range");
     if (B > 65535) return fail(GCS_EINVAL, "gcs_gabor_features: B too large for one launch");
     const int pitch = (int)gcs_feature_pitch(W);
+    const size_t pstride = gcs_feature_plane_stride(H, W);
     const int tiles_x = (W + G_TW - 1) / G_TW, tiles_y = (H + G_TH - 1) / G_TH;
     const int Hp = gabor_hp(H), Wp = gabor_wp(W);
     if (Hp > 65535) return fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
@@ -346,26 +370,27 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
         if (n == 3)
             hipLaunchKernelGGL(gabor_mfma_kernel<3>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, tiles_x);
+                               F, shift, feats, pitch, pstride, tiles_x);
         else if (n == 2)
             hipLaunchKernelGGL(gabor_mfma_kernel<2>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, tiles_x);
+                               F, shift, feats, pitch, pstride, tiles_x);
         else
             hipLaunchKernelGGL(gabor_mfma_kernel<1>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, tiles_x);
+                               F, shift, feats, pitch, pstride, tiles_x);
         GCS_CHECK_LAUNCH("gcs_gabor_features");
     }
     return GCS_OK;
 }
 
 // ------------------------------------------------------------------------------- unpack
-__global__ void unpack_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, size_t planes,
-                              uint16_t *__restrict__ out) {
+__global__ void unpack_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, size_t pstride,
+                              size_t planes, size_t planes_per_image, uint16_t *__restrict__ out) {
     const size_t n = planes * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pl = i / ((size_t)H * W);
         const int rem = (int)(i % ((size_t)H * W));
-        out[i] = feats[(pl * H + rem / W) * pitch + rem % W];
+        const int D_ = (int)(planes_per_image);
+        out[i] = feats[slab_index((pl / D_) * (pstride >> 8), D_, (int)(pl % D_), (rem / W) * pitch + rem % W)] ^ 0x8080u;
     }
 }
 
@@ -374,21 +399,21 @@ extern "C" int gcs_features_unpack(const uint16_t *feats, int B, int H, int W, i
     if (!feats || !out) return fail(GCS_EINVAL, "gcs_features_unpack: NULL pointer");
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return fail(GCS_EINVAL, "gcs_features_unpack: bad shape");
     hipLaunchKernelGGL(unpack_kernel, dim3(2048), dim3(256), 0, stream, feats, H, W,
-                       (int)gcs_feature_pitch(W), (size_t)B * D, out);
+                       (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), (size_t)B * D, (size_t)D, out);
     GCS_CHECK_LAUNCH("gcs_features_unpack");
     return GCS_OK;
 }
 
 // =============================================================================== k-means
-__global__ void kmeans_init_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, int D, int k,
-                                   uint16_t *__restrict__ cent) {
+__global__ void kmeans_init_kernel(const uint16_t *__restrict__ feats, int H, int W, int pitch, size_t pstride,
+                                   int D, int k, uint16_t *__restrict__ cent) {
     const int set = blockIdx.x; // image index == set index (n_sets == 1 -> image 0)
     const long P = (long)H * W;
     for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
         const int j = i / D, d = i % D;
         const long p = ((2L * j + 1) * P) / (2L * k);
         const int y = (int)(p / W), x = (int)(p % W);
-        cent[((size_t)set * k + j) * D + d] = feats[(((size_t)set * D + d) * H + y) * pitch + x];
+        cent[((size_t)set * k + j) * D + d] = feats[slab_index((size_t)set * (pstride >> 8), D, d, y * pitch + x)] ^ 0x8080u;
     }
 }
 
@@ -399,7 +424,7 @@ extern "C" int gcs_kmeans_init(const uint16_t *feats, int B, int H, int W, int D
     if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_init: k must be in 1..16");
     if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_init: n_sets must be 1 or B");
     hipLaunchKernelGGL(kmeans_init_kernel, dim3(n_sets), dim3(256), 0, stream, feats, H, W,
-                       (int)gcs_feature_pitch(W), D, k, cent);
+                       (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), D, k, cent);
     GCS_CHECK_LAUNCH("gcs_kmeans_init");
     return GCS_OK;
 }
@@ -412,8 +437,8 @@ constexpr int KM_CHUNK = 128;
 
 template <int K>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(
-    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int D,
-    int per_image, int parts, int R, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, size_t plane,
+    int D, int per_image, int parts, int R, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: cdig float [D][K][2] | cnorm int64 [K] | acc u32 [K][D+1][R]
     float *cdig = reinterpret_cast<float *>(smem);
@@ -444,13 +469,12 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
 
     const int ppr = pitch >> 1; // pixel pairs per row
     const long npairs = (long)H * ppr;
-    const size_t plane = (size_t)H * pitch;
-    const uint16_t *fb = feats + (size_t)b * D * plane;
+    const size_t tile0 = (size_t)b * (plane >> 8);          // slab holds x ^ 0x8080, tile-major
     const int rep = tid & (R - 1);
 
     for (long q = (long)part * 256 + tid; q < npairs; q += (long)parts * 256) {
         const int y = (int)(q / ppr), x = 2 * (int)(q % ppr);
-        const size_t off = (size_t)y * pitch + x;
+        const int off = y * pitch + x;
         long long S[2][K];
 #pragma unroll
         for (int j = 0; j < K; ++j) S[0][j] = S[1][j] = 0;
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
 #pragma unroll
             for (int j = 0; j < K; ++j) a0[0][j] = a0[1][j] = a1[0][j] = a1[1][j] = a2[0][j] = a2[1][j] = 0.f;
             for (int d = d0; d < d1; ++d) {
-                const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                const unsigned u = *reinterpret_cast<const unsigned *>(feats + slab_index(tile0, D, d, off)) ^ 0x80808080u;
                 const float xl0 = (float)(u & 255u), xh0 = (float)((u >> 8) & 255u);
                 const float xl1 = (float)((u >> 16) & 255u), xh1 = (float)(u >> 24);
                 const float *cd = cdig + d * K * 2;
@@ -497,7 +521,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
             }
             lab[p] = bj;
         }
-        *reinterpret_cast<uint16_t *>(labels + ((size_t)b * H + y) * pitch + x) =
+        *reinterpret_cast<uint16_t *>(labels + (size_t)b * plane + (size_t)y * pitch + x) =
             (uint16_t)(lab[0] | (lab[1] << 8));
         // accumulate (second pass over this thread's planes; L2-resident)
         const bool v0 = x < W, v1 = x + 1 < W;
@@ -506,13 +530,13 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
             unsigned *a_1 = acc + (size_t)lab[1] * D1 * R + rep;
             if (v1 && lab[0] == lab[1]) {
                 for (int d = 0; d < D; ++d) {
-                    const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                    const unsigned u = *reinterpret_cast<const unsigned *>(feats + slab_index(tile0, D, d, off)) ^ 0x80808080u;
                     atomicAdd(a_0 + d * R, (u & 0xffffu) + (u >> 16));
                 }
                 atomicAdd(a_0 + D * R, 2u);
             } else {
                 for (int d = 0; d < D; ++d) {
-                    const unsigned u = *reinterpret_cast<const unsigned *>(fb + (size_t)d * plane + off);
+                    const unsigned u = *reinterpret_cast<const unsigned *>(feats + slab_index(tile0, D, d, off)) ^ 0x80808080u;
                     atomicAdd(a_0 + d * R, u & 0xffffu);
                     if (v1) atomicAdd(a_1 + d * R, u >> 16);
                 }
@@ -546,12 +570,15 @@ constexpr int KP_ROWS = 80;               // plane rows held in LDS
 constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
 constexpr int KP_DSTEPS = KP_ROWS / 16;   // assign K-steps: 16 planes = 32 byte-features each
 constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-planes each
-constexpr int KP_NST = KP_ROWS * (KP_TP / 8) / 256;  // 16-byte staging chunks per thread
 
-template <int KT>
-__global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
-    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int D,
-    int K, int per_image, int parts, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+#ifndef GCS_KP_WAVES
+#define GCS_KP_WAVES 3
+#endif
+template <int KT, int NST>   // NST = 16-byte staging chunks per thread = ceil(D / 8)
+__global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
+    const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
+    int D, int K, int per_image, int parts, int x_first, int x_step, uint8_t *__restrict__ labels,
+    uint64_t *__restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
@@ -559,9 +586,9 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, part = blockIdx.x;
     const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
-    const int npix = H * pitch;
-    const int ntiles = (npix + KP_TP - 1) / KP_TP;
-    const uint16_t *fb = feats + (size_t)b * D * npix;
+    const int npix = H * pitch;                      // pixels that exist (pad columns included)
+    const int ntiles = pstride / KP_TP;              // plane stride is a whole number of tiles
+    const uint16_t *fb = feats + (size_t)b * ntiles * D * KP_TP;   // this image's tiles, each D*256 contiguous
 
     // ---- per-cluster constant: |c|^2 - 2*(offset terms of the -128 digits), exact int64
     if (tid < 16) {
@@ -580,6 +607,8 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
         }
         s_const[tid] = cst;
     }
+    // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
+    if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
     // ---- assign A fragments: row r = 4*jj + pat of tile mt (cluster j = 8*mt + jj);
     //      k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2, byte t&1)
     v4i apat[KT][KP_DSTEPS];
@@ -613,34 +642,30 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
 #pragma unroll
     for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
 
-    // ---- staging: chunk ci = tid + 256*i -> plane ci>>5, pixels 8*(ci&31) .. +7 of the tile
-    v4i st[KP_NST];
+    // ---- staging: the tile is ONE contiguous D*512-byte run of the slab (tile-major layout, already
+    //      offset-binary): chunk ci = tid + 256*i is 16 bytes at byte 16*ci -> plane ci>>5, pixels 8*(ci&31)..
+    const int sd0 = tid >> 5, spo = 8 * (tid & 31);
+    v4i st[NST];
     auto stage_load = [&](int tile) {
-        const int pp0 = tile * KP_TP;
+        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * D * KP_TP) + tid;
 #pragma unroll
-        for (int i = 0; i < KP_NST; ++i) {
-            const int ci = tid + 256 * i;
-            const int d = ci >> 5, po = 8 * (ci & 31);
-            v4i v = {0, 0, 0, 0};
-            if (d < D && pp0 + po < npix) v = *reinterpret_cast<const v4i *>(fb + (size_t)d * npix + pp0 + po);
-            st[i] = v;
-        }
+        for (int i = 0; i < NST; ++i)
+            if (sd0 + 8 * i < D) st[i] = src[256 * i];
     };
     auto stage_write = [&]() {
+        unsigned char *dst = &s_tile[sd0 * KP_PITCH + spo * 2];
 #pragma unroll
-        for (int i = 0; i < KP_NST; ++i) {
-            const int ci = tid + 256 * i;
-            const int d = ci >> 5, po = 8 * (ci & 31);
-            v4i v = st[i];
-            v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
-            *reinterpret_cast<v4i *>(&s_tile[d * KP_PITCH + po * 2]) = v;
-        }
+        for (int i = 0; i < NST; ++i)
+            if (sd0 + 8 * i < D) *reinterpret_cast<v4i *>(dst + (8 * i) * KP_PITCH) = st[i];
     };
 
     const int un = lane & 15, ug = lane >> 4;             // update operand coordinates
     const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
-    const int cnt_bp = 2 * D;                              // the all-ones byte-plane
     const unsigned eqr = (unsigned)un * 0x01010101u;
+    const int cnt_bp = 2 * D;
+
+    // x coordinate of the tile's first pixel, advanced without divisions (x_step = (parts*256) % pitch)
+    int x0 = (int)(((long long)part * x_first) % pitch);   // x_first = 256 % pitch; once per workgroup
 
     int tile = part;
     if (tile < ntiles) stage_load(tile);
@@ -650,6 +675,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
         if (tile + parts < ntiles) stage_load(tile + parts);   // in flight during the MFMAs
 
         const int pp0 = tile * KP_TP;
+#ifdef GCS_ABL_KP_STREAMONLY
+        {   // timing-only build: touch the staged tile, skip assign/update
+            const v4i t0 = *reinterpret_cast<const v4i *>(&s_tile[(tid & 63) * KP_PITCH + (tid >> 6) * 16]);
+            accu[0][0] += t0[0] ^ t0[1] ^ t0[2] ^ t0[3];
+            __syncthreads();
+            continue;
+        }
+#endif
         // -------- assign: two 32-pixel sub-tiles per wave
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -692,13 +725,21 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
             const long long pb = __shfl_xor(best, 32);
             const int pj = __shfl_xor(bj, 32);
             if (pb < best || (pb == best && pj < bj)) bj = pj;
-            const int pp = pp0 + pl;
             if (h == 0) {
-                const bool valid = pp < npix && (pp % pitch) < W;
+                const int pp = pp0 + pl;
+                int x = x0 + pl;                     // pixel column: at most ceil(256/pitch)+1 wraps
+                if (pitch >= KP_TP) {
+                    if (x >= pitch) x -= pitch;
+                } else {
+                    x %= pitch;
+                }
+                const bool valid = pp < npix && x < W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
-                if (pp < npix) labels[(size_t)b * npix + pp] = (uint8_t)bj;
+                labels[(size_t)b * pstride + pp] = (uint8_t)bj;
             }
         }
+        x0 += x_step;
+        if (x0 >= pitch) x0 -= pitch;
         // -------- update: one-hot MFMA over this wave's 64 pixels
         {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
@@ -719,7 +760,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_mfma_kernel(
                 bx[1] = (int)__builtin_amdgcn_perm((unsigned)w0[3], (unsigned)w0[2], usel);
                 bx[2] = (int)__builtin_amdgcn_perm((unsigned)w1[1], (unsigned)w1[0], usel);
                 bx[3] = (int)__builtin_amdgcn_perm((unsigned)w1[3], (unsigned)w1[2], usel);
-                if (16 * nt + un == cnt_bp) bx = v4i{0x01010101, 0x01010101, 0x01010101, 0x01010101};
                 accu[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx, accu[nt], 0, 0, 0);
             }
         }
@@ -759,7 +799,7 @@ static size_t assign_lds_bytes(int D, int k, int R) {
 template <int K>
 static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int D, int n_sets,
                          uint8_t *labels, uint64_t *partials, hipStream_t stream) {
-    const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+    const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     int R = 32;
     while (R > 1 && assign_lds_bytes(D, K, R) > 120 * 1024) R >>= 1;
     const size_t lds = assign_lds_bytes(D, K, R);
@@ -772,7 +812,7 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int
         lds_granted = lds;
     }
     hipLaunchKernelGGL(kmeans_assign_kernel<K>, dim3(parts, B), dim3(256), lds, stream, feats, cent, H, W,
-                       (int)gcs_feature_pitch(W), D, n_sets == B ? 1 : 0, parts, R,
+                       (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), D, n_sets == B ? 1 : 0, parts, R,
                        labels, partials);
     GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
     return GCS_OK;
@@ -789,15 +829,26 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     if (n_sets != 1 && n_sets != B)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
     if (D < KP_ROWS) { // matrix-core pass (the product path for every BASELINE bank with F <= 26)
-        const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+        const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
         const int pitch = (int)gcs_feature_pitch(W);
         if ((long long)H * pitch > 0x7fffffffLL / 2) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large");
-        if (k <= 8)
-            hipLaunchKernelGGL(kmeans_pass_mfma_kernel<1>, dim3(parts, B), dim3(256), 0, stream, feats, cent, H, W,
-                               pitch, D, k, n_sets == B ? 1 : 0, parts, labels, partials);
-        else
-            hipLaunchKernelGGL(kmeans_pass_mfma_kernel<2>, dim3(parts, B), dim3(256), 0, stream, feats, cent, H, W,
-                               pitch, D, k, n_sets == B ? 1 : 0, parts, labels, partials);
+        const int pstride = (int)gcs_feature_plane_stride(H, W);
+        // NOTE: the kernel derives each workgroup's first x from part; x_first is per-part below
+#define GCS_KP_LAUNCH(KT_, NST_)                                                                              \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_>), dim3(parts, B), dim3(256), 0, stream, feats, cent, H, \
+                       W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, KP_TP % pitch,                         \
+                       (int)(((long long)parts * KP_TP) % pitch), labels, partials)
+        const int nst = (D + 7) / 8;
+        if (k <= 8) {
+            if (nst <= 3) GCS_KP_LAUNCH(1, 3);
+            else if (nst <= 6) GCS_KP_LAUNCH(1, 6);
+            else if (nst <= 9) GCS_KP_LAUNCH(1, 9);
+            else GCS_KP_LAUNCH(1, 10);
+        } else {
+            if (nst <= 9) GCS_KP_LAUNCH(2, 9);
+            else GCS_KP_LAUNCH(2, 10);
+        }
+#undef GCS_KP_LAUNCH
         GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
         return GCS_OK;
     }
@@ -843,7 +894,7 @@ extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, 
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX)
         return fail(GCS_EINVAL, "gcs_kmeans_reduce: bad shape");
     if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_reduce: n_sets must be 1 or B");
-    const int parts = (int)gcs_kmeans_parts_per_image(H, W);
+    const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
@@ -873,11 +924,11 @@ extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D
     return GCS_OK;
 }
 
-__global__ void widen_kernel(const uint8_t *__restrict__ labels, int H, int W, int pitch, size_t n,
+__global__ void widen_kernel(const uint8_t *__restrict__ labels, int H, int W, int pitch, size_t pstride, size_t n,
                              int32_t *__restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t by = i / W; // b*H + y
-        out[i] = labels[by * pitch + i % W];
+        out[i] = labels[(by / H) * pstride + (by % H) * pitch + i % W];
     }
 }
 
@@ -885,7 +936,7 @@ extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int3
     if (!labels || !out) return fail(GCS_EINVAL, "gcs_labels_widen: NULL pointer");
     if (B <= 0 || H <= 0 || W <= 0) return fail(GCS_EINVAL, "gcs_labels_widen: bad shape");
     hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, stream, labels, H, W, (int)gcs_feature_pitch(W),
-                       (size_t)B * H * W, out);
+                       gcs_feature_plane_stride(H, W), (size_t)B * H * W, out);
     GCS_CHECK_LAUNCH("gcs_labels_widen");
     return GCS_OK;
 }

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 2
+#define GCS_ABI_VERSION 4
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -50,13 +50,16 @@ size_t gcs_bank_bias_count(int n_filters);
  * (pixels are fed as img-128). Replaces nothing in the reference (bank absent). */
 int gcs_bank_pack(const int16_t *tapq, int n_filters, int ksize, int8_t *packed, int32_t *bias);
 
-/* Feature slab geometry: uint16 planes [B][D][H][pitch], pitch = W rounded up to 8 pixels.
- * The slab is opaque to callers; gcs_features_unpack gives the canonical layout. */
+/* Feature slab geometry: tile-major [B][plane_stride/256][D][256 px] uint16, stored offset-binary
+ * (x ^ 0x8080: both bytes are signed MFMA digits), rows of `pitch` = W rounded up to 8 pixels,
+ * plane_stride = H*pitch rounded up to 256 pixels. The slab is opaque to callers;
+ * gcs_features_unpack gives the canonical [B][D][H][W] uint16 layout. */
 size_t gcs_feature_pitch(int W);
+size_t gcs_feature_plane_stride(int H, int W);
 size_t gcs_feature_slab_bytes(int B, int H, int W, int D);
-size_t gcs_label_slab_bytes(int B, int H, int W); /* uint8 [B][H][pitch] */
+size_t gcs_label_slab_bytes(int B, int H, int W); /* uint8 [B][plane_stride] */
 /* uint64 partial-sum rows written by one assign pass: [B][parts][k][D+1]. */
-size_t gcs_kmeans_parts_per_image(int H, int W);
+size_t gcs_kmeans_parts_per_image(int B, int H, int W);
 size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 
 /* ---- device entry points ---------------------------------------------------------------- */

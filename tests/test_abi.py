@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 2
+    assert lib.gcs_abi_version() == 4
 
 
 def test_no_torch_types_in_the_abi():
@@ -32,13 +32,17 @@ def test_no_torch_types_in_the_abi():
 
 def test_geometry(lib):
     assert lib.gcs_feature_pitch(481) == 488 and lib.gcs_feature_pitch(321) == 328 and lib.gcs_feature_pitch(8) == 8
-    assert lib.gcs_feature_slab_bytes(64, 321, 481, 72) == 64 * 72 * 321 * 488 * 2
-    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * 321 * 488
+    ps = lib.gcs_feature_plane_stride(321, 481)
+    assert ps % 256 == 0 and 0 <= ps - 321 * 488 < 256
+    assert lib.gcs_feature_slab_bytes(64, 321, 481, 72) == 64 * 72 * ps * 2
+    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * ps
     assert lib.gcs_bank_packed_bytes(24) == 3 * 8 * 64 * 16 and lib.gcs_bank_packed_bytes(1) == 8 * 64 * 16
     assert lib.gcs_bank_bias_count(24) == 24 and lib.gcs_bank_bias_count(25) == 32
-    p = lib.gcs_kmeans_parts_per_image(321, 481)
-    assert 1 <= p <= 16 and 321 * 488 / p <= 65536
-    assert lib.gcs_kmeans_parts_per_image(2048, 2048) * 65536 >= 2048 * 2048
+    p = lib.gcs_kmeans_parts_per_image(64, 321, 481)
+    assert p == 12 and 321 * 488 / p <= 65536                 # 64 * 12 = 768 workgroups = 256 CUs x 3
+    assert lib.gcs_kmeans_parts_per_image(1, 321, 481) * 8 * 256 <= ps          # >= 8 tiles per workgroup
+    assert lib.gcs_kmeans_parts_per_image(1, 2048, 2048) * 65536 >= 2048 * 2048
+    assert lib.gcs_kmeans_parts_per_image(4096, 321, 481) * 65536 >= 321 * 488
     assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * 8 * 73 * 8
     assert lib.gcs_feature_slab_bytes(0, 1, 1, 1) == 0
 
