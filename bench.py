@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU, help="images per GPU")
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--also-other-mode", action="store_true", help="also time the other codebook mode (extra key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
@@ -176,9 +177,25 @@ def main():
         roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ka["hbm_frac"], traffic=None)
 
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
+    # command (tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no profile matches.
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
+        cand = [e for e in prof.get(roofline["kernel"], []) if e["launches"] > 0]
+        if roofline["kernel"] == "gabor_mfma_kernel":
+            big = max(e["grid_threads"] for e in cand)
+            roofline["traffic"] = sum(e["hbm_bytes_corrected"] for e in cand if e["grid_threads"] == big) + \
+                sum(e["hbm_bytes_corrected"] for e in prof.get("gabor_pad_kernel", [])
+                    if e["grid_threads"] == max(x["grid_threads"] for x in prof["gabor_pad_kernel"]))
+        else:
+            roofline["traffic"] = max(cand, key=lambda e: e["grid_threads"])["hbm_bytes_corrected"]
+        roofline["traffic_source"] = "profiles/hbm_traffic_latest.json (separate rocprofv3 --pmc run, batch %d)" % PER_GPU
+    except Exception:
+        pass
+
     extra = {}
     other = "per_image" if args.mode == "global" else "global"
-    if world == 1:
+    if world == 1 and args.also_other_mode:
         dt2 = timed(other, max(1, args.steps // 2), 1, events=False)
         extra[f"{other}_mpix_s"] = round(px * max(1, args.steps // 2) / dt2 / 1e6, 1)
 

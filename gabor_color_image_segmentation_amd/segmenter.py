@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from .bank import GaborBank, make_bank
 
-_SLAB_BUDGET = 192 << 20   # per-image mode: keep a group's feature slab Infinity-Cache sized
+_SLAB_BUDGET = 16 << 30    # feature-slab bytes per group; measured: one big launch beats cache-sized groups
 
 
 def _torch():

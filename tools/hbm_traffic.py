@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of the two streaming kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE.
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced streaming reads, so it is
+doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores. Only the batch-64 launches
+(the configuration bench.py times) are averaged.
+"""
+import csv, glob, json, sys, collections
+out_dir, dst = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        key = "gabor_mfma_kernel" if "gabor_mfma_kernel" in n else "kmeans_pass_mfma_kernel" if "kmeans_pass_mfma" in n else \
+              "gabor_pad_kernel" if "gabor_pad" in n else None
+        if key:
+            acc[(key, n.split("(")[0].split()[-1], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for (key, full, grid), cs in sorted(acc.items()):
+    f = cs.get("FETCH_SIZE", []); w = cs.get("WRITE_SIZE", [])
+    res.setdefault(key, []).append(dict(kernel=full, grid_threads=grid, launches=len(f),
+        fetch_kib_raw=sum(f) / max(1, len(f)), write_kib=sum(w) / max(1, len(w)),
+        hbm_bytes_corrected=int((2 * sum(f) / max(1, len(f)) + sum(w) / max(1, len(w))) * 1024)))
+json.dump(res, open(dst, "w"), indent=1)
