@@ -270,13 +270,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                             bf[j] = (t == 0) ? win[kk][j]
                                              : (int)__builtin_amdgcn_alignbyte((unsigned)win[kk][j + 1],
                                                                                (unsigned)win[kk][j], t);
-#ifdef GCS_ABL_NOMFMA
-                        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] += bf[0] + afr[mt][kk][0]; acc[mt][5] += bf[1]; acc[mt][10] += bf[2] ^ afr[mt][kk][1]; acc[mt][15] += bf[3]; }
-#else
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
-#endif
                     }
                     // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter.
                     // All 4*MT magnitudes are computed as independent chains (ILP), then pinned.
@@ -288,11 +284,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                             const int a_re = ((acc[mt][4 * g + 1] << 8) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
                             const int a_im = ((acc[mt][4 * g + 3] << 8) + acc[mt][4 * g + 2]) >> shift;
                             const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
-#ifdef GCS_ABL_NOEPI
-                            mag[mt][g] = (unsigned)(acc[mt][4 * g] ^ acc[mt][4 * g + 1] ^ acc[mt][4 * g + 2] ^ acc[mt][4 * g + 3]) & 0xffffu; (void)n;
-#else
                             mag[mt][g] = isqrt31(n);
-#endif
                         }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -314,11 +306,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             // 8 consecutive pixels x = x0 + 8*li .. +7 of row oy: one 16-byte store per filter;
             // the 8 li-lanes of a row cover 128 contiguous bytes
             const int oy = y0 + trow, ox = x0 + 8 * li;
-#ifdef GCS_ABL_NOSTORE
-            if (oy < H && ox < pitch && shift == 77) {
-#else
             if (oy < H && ox < pitch) {
-#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -675,14 +663,6 @@ __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass
         if (tile + parts < ntiles) stage_load(tile + parts);   // in flight during the MFMAs
 
         const int pp0 = tile * KP_TP;
-#ifdef GCS_ABL_KP_STREAMONLY
-        {   // timing-only build: touch the staged tile, skip assign/update
-            const v4i t0 = *reinterpret_cast<const v4i *>(&s_tile[(tid & 63) * KP_PITCH + (tid >> 6) * 16]);
-            accu[0][0] += t0[0] ^ t0[1] ^ t0[2] ^ t0[3];
-            __syncthreads();
-            continue;
-        }
-#endif
         // -------- assign: two 32-pixel sub-tiles per wave
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {

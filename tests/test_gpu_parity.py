@@ -87,3 +87,23 @@ def test_global_codebook_bit_exact(torch_cuda):
     got = Segmenter(n_iter=5).segment_batch(imgs, mode="global")
     ref = so.segment_batch(imgs, mode="global", n_iter=5)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("ns,no,ks,k", [(1, 1, 15, 3), (1, 4, 9, 5), (2, 5, 11, 8), (3, 8, 15, 16), (2, 13, 7, 4)])
+def test_segment_small_and_ragged_feature_counts(torch_cuda, ns, no, ks, k):
+    """D = 3, 12, 30, 72, 78: every staging-chunk bucket of the MFMA k-means pass, D not a multiple of 8."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    imgs = _synth(2, 40, 72, seed=31)
+    seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=4)
+    got = seg.segment_batch(imgs)
+    for b in range(2):
+        assert np.array_equal(got[b], so.segment(imgs[b], n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=4))
+
+
+def test_images_narrower_than_a_kmeans_tile(torch_cuda):
+    """pitch < 256: a 256-pixel tile spans several rows (the modulo path of the validity test)."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    imgs = _synth(2, 70, 19, seed=5)
+    seg = Segmenter(n_iter=3, k=4)
+    got = seg.segment_batch(imgs, mode="global")
+    assert np.array_equal(got, so.segment_batch(imgs, mode="global", k=4, n_iter=3))
