@@ -417,6 +417,28 @@ extern "C" int gcs_kmeans_init(const uint16_t *feats, int B, int H, int W, int D
     return GCS_OK;
 }
 
+// out[i][d] = feature d of pixel (b, y, x) = byx[i]; b < 0 gives a zero row. Lets a rank publish the
+// SPEC.md §4 init centroids it owns when an image is sharded by rows (BASELINE config 5).
+__global__ void features_gather_kernel(const uint16_t *__restrict__ feats, int pitch, size_t pstride, int D, int n,
+                                       const int32_t *__restrict__ byx, uint16_t *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * D; i += gridDim.x * blockDim.x) {
+        const int r = i / D, d = i % D;
+        const int b = byx[3 * r], y = byx[3 * r + 1], x = byx[3 * r + 2];
+        out[i] = b < 0 ? (uint16_t)0
+                       : (uint16_t)(feats[slab_index((size_t)b * (pstride >> 8), D, d, y * pitch + x)] ^ 0x8080u);
+    }
+}
+
+extern "C" int gcs_features_gather(const uint16_t *feats, int B, int H, int W, int D, int n, const int32_t *byx,
+                                   uint16_t *out, gcs_stream_t stream) {
+    if (!feats || !byx || !out) return fail(GCS_EINVAL, "gcs_features_gather: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || n <= 0) return fail(GCS_EINVAL, "gcs_features_gather: bad shape");
+    hipLaunchKernelGGL(features_gather_kernel, dim3((n * D + 255) / 256), dim3(256), 0, stream, feats,
+                       (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), D, n, byx, out);
+    GCS_CHECK_LAUNCH("gcs_features_gather");
+    return GCS_OK;
+}
+
 // Exact integer argmin with fp32 digit arithmetic: x = 256*xh + xl, c = 256*ch + cl (bytes);
 //   sum_d x*c = 65536*sum xh*ch + 256*sum (xh*cl + xl*ch) + sum xl*cl,
 // every partial sum stays below 2^24 over a chunk of <= 128 planes, so fp32 FMA is exact.
@@ -426,7 +448,8 @@ constexpr int KM_CHUNK = 128;
 template <int K>
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, size_t plane,
-    int D, int per_image, int parts, int R, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    int D, int per_image, int parts, int R, int row_lo, int row_hi, uint8_t *__restrict__ labels,
+    uint64_t *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: cdig float [D][K][2] | cnorm int64 [K] | acc u32 [K][D+1][R]
     float *cdig = reinterpret_cast<float *>(smem);
@@ -512,7 +535,8 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         *reinterpret_cast<uint16_t *>(labels + (size_t)b * plane + (size_t)y * pitch + x) =
             (uint16_t)(lab[0] | (lab[1] << 8));
         // accumulate (second pass over this thread's planes; L2-resident)
-        const bool v0 = x < W, v1 = x + 1 < W;
+        const bool rows_ok = y >= row_lo && y < row_hi;
+        const bool v0 = rows_ok && x < W, v1 = rows_ok && x + 1 < W;
         if (v0) {
             unsigned *a_0 = acc + (size_t)lab[0] * D1 * R + rep;
             unsigned *a_1 = acc + (size_t)lab[1] * D1 * R + rep;
@@ -565,8 +589,8 @@ constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-
 template <int KT, int NST>   // NST = 16-byte staging chunks per thread = ceil(D / 8)
 __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
-    int D, int K, int per_image, int parts, int x_first, int x_step, uint8_t *__restrict__ labels,
-    uint64_t *__restrict__ partials) {
+    int D, int K, int per_image, int parts, int x_first, int x_step, int row_lo, int row_hi,
+    uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
@@ -574,7 +598,7 @@ __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, part = blockIdx.x;
     const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
-    const int npix = H * pitch;                      // pixels that exist (pad columns included)
+    const int p_lo = row_lo * pitch, p_hi = row_hi * pitch;   // pixels that vote: rows [row_lo, row_hi)
     const int ntiles = pstride / KP_TP;              // plane stride is a whole number of tiles
     const uint16_t *fb = feats + (size_t)b * ntiles * D * KP_TP;   // this image's tiles, each D*256 contiguous
 
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass
                 } else {
                     x %= pitch;
                 }
-                const bool valid = pp < npix && x < W;
+                const bool valid = pp >= p_lo && pp < p_hi && x < W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
                 labels[(size_t)b * pstride + pp] = (uint8_t)bj;
             }
@@ -778,7 +802,7 @@ static size_t assign_lds_bytes(int D, int k, int R) {
 
 template <int K>
 static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int D, int n_sets,
-                         uint8_t *labels, uint64_t *partials, hipStream_t stream) {
+                         int row_lo, int row_hi, uint8_t *labels, uint64_t *partials, hipStream_t stream) {
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     int R = 32;
     while (R > 1 && assign_lds_bytes(D, K, R) > 120 * 1024) R >>= 1;
@@ -793,16 +817,18 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int
     }
     hipLaunchKernelGGL(kmeans_assign_kernel<K>, dim3(parts, B), dim3(256), lds, stream, feats, cent, H, W,
                        (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), D, n_sets == B ? 1 : 0, parts, R,
-                       labels, partials);
+                       row_lo, row_hi, labels, partials);
     GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
     return GCS_OK;
 }
 
 extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
-                                            int D, int k, int n_sets, uint8_t *labels, uint64_t *partials,
-                                            gcs_stream_t stream) {
+                                            int D, int k, int n_sets, int row_lo, int row_hi, uint8_t *labels,
+                                            uint64_t *partials, gcs_stream_t stream) {
     if (!feats || !cent || !labels || !partials)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer");
+    if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
+        return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: need 0 <= row_lo < row_hi <= H");
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || B > 65535)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: bad shape");
     if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
@@ -817,7 +843,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 #define GCS_KP_LAUNCH(KT_, NST_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_>), dim3(parts, B), dim3(256), 0, stream, feats, cent, H, \
                        W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, KP_TP % pitch,                         \
-                       (int)(((long long)parts * KP_TP) % pitch), labels, partials)
+                       (int)(((long long)parts * KP_TP) % pitch), row_lo, row_hi, labels, partials)
         const int nst = (D + 7) / 8;
         if (k <= 8) {
             if (nst <= 3) GCS_KP_LAUNCH(1, 3);
@@ -835,7 +861,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     switch (k) { // generic VALU pass for wider feature vectors
 #define GCS_CASE(KK) \
     case KK:         \
-        return launch_assign<KK>(feats, cent, B, H, W, D, n_sets, labels, partials, stream);
+        return launch_assign<KK>(feats, cent, B, H, W, D, n_sets, row_lo, row_hi, labels, partials, stream);
         GCS_CASE(1) GCS_CASE(2) GCS_CASE(3) GCS_CASE(4) GCS_CASE(5) GCS_CASE(6) GCS_CASE(7) GCS_CASE(8)
         GCS_CASE(9) GCS_CASE(10) GCS_CASE(11) GCS_CASE(12) GCS_CASE(13) GCS_CASE(14) GCS_CASE(15) GCS_CASE(16)
 #undef GCS_CASE

@@ -87,10 +87,20 @@ class HipOps:
         _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
                                             cent.data_ptr(), self._stream()), "gcs_kmeans_init")
 
-    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials):
+    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None):
+        lo, hi = rows if rows is not None else (0, h)
         _lib.check(self.lib.gcs_kmeans_assign_accumulate(
-            feats.data_ptr(), cent.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
+            feats.data_ptr(), cent.data_ptr(), b, h, w, self.bank.n_features, k, n_sets, lo, hi,
             labels.data_ptr(), partials.data_ptr(), self._stream()), "gcs_kmeans_assign_accumulate")
+
+    def features_gather(self, feats, b, h, w, byx):
+        """byx: (n,3) int32 device tensor of (image, row, col); image < 0 -> zero row. -> (n,D) int16."""
+        n = byx.shape[0]
+        out = self.torch.empty((n, self.bank.n_features), dtype=self.torch.int16, device=self.device)
+        _lib.check(self.lib.gcs_features_gather(feats.data_ptr(), b, h, w, self.bank.n_features, n,
+                                                byx.data_ptr(), out.data_ptr(), self._stream()),
+                   "gcs_features_gather")
+        return out
 
     def reduce(self, partials, b, h, w, k, n_sets, sums):
         _lib.check(self.lib.gcs_kmeans_reduce(partials.data_ptr(), b, h, w, self.bank.n_features, k,
@@ -113,12 +123,26 @@ class HipOps:
                                 device=self.device)
 
 
-def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None):
+def _collective(fn, t, **kw):
+    """Run a torch.distributed collective on a small tensor; gloo gets a host copy of device tensors."""
+    import torch.distributed as td
+    if t.is_cuda and td.get_backend(kw.get("group")) == "gloo":
+        tmp = t.cpu()
+        fn(tmp, **kw)
+        t.copy_(tmp)
+    else:
+        fn(t, **kw)
+
+
+def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None,
+          rows=None, init=None):
     """SPEC.md §4 schedule on one feature slab. ``mode``: 'per_image' or 'global'.
 
     In 'global' mode with torch.distributed initialised, the init centroids come from
     rank 0 (its image 0 is image 0 of the global batch) and the int64 sums are all-reduced
     (RCCL on GPU, any order: integer sums are exact). One collective per Lloyd pass.
+    ``rows=(lo, hi)``: only these rows of every image vote (row-sharded images, halo rows
+    excluded); ``init(cent)``: custom centroid initialisation (row-sharded images).
     """
     n_sets = b if mode == "per_image" else 1
     dist = None
@@ -126,19 +150,30 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
         import torch.distributed as td
         if td.is_available() and td.is_initialized() and td.get_world_size(dist_group) > 1:
             dist = td
-    ops.kmeans_init(feats, b, h, w, k, n_sets, cent)
-    if dist is not None:
-        # RCCL / gloo have no 16-bit integer type: move the centroid bytes
-        dist.broadcast(cent.view(ops.torch.uint8) if hasattr(ops, "torch") else cent.view(_torch().uint8),
-                       src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
-                       group=dist_group)
+    if init is not None:
+        init(cent)
+    else:
+        ops.kmeans_init(feats, b, h, w, k, n_sets, cent)
+        if dist is not None:
+            # RCCL / gloo have no 16-bit integer type: move the centroid bytes
+            _collective(dist.broadcast, cent.view(_torch().uint8),
+                        src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
+                        group=dist_group)
     for t in range(n_iter):
-        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials)
+        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows)
         if t < n_iter - 1:
             ops.reduce(partials, b, h, w, k, n_sets, sums)
             if dist is not None:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=dist_group)
+                _collective(dist.all_reduce, sums, op=dist.ReduceOp.SUM, group=dist_group)
             ops.finalize(sums, n_sets, k, cent)
+
+
+def shard_rows(height: int, world: int, rank: int, halo: int = 7):
+    """Row strip of rank ``rank``: owned global rows [r0, r1) and the strip [s0, s1) that also
+    carries up to ``halo`` real neighbour rows on interior edges (BASELINE config 5)."""
+    r0 = (height * rank) // world
+    r1 = (height * (rank + 1)) // world
+    return r0, r1, max(0, r0 - halo), min(height, r1 + halo)
 
 
 class Segmenter:
@@ -203,6 +238,54 @@ class Segmenter:
         return dict(feats=self.ops.feature_slab(n, h, w), labels=self.ops.label_slab(n, h, w),
                     partials=self.ops.partial_slab(n, h, w, self.k),
                     cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
+
+    def segment_rows_sharded_device(self, strip, r0, r1, s0, height, dist_group=None, out=None):
+        """Row-sharded images with one global codebook (BASELINE config 5).
+
+        ``strip``: (B, s1-s0, W, 3) uint8 device tensor = global rows [s0, s1) of B images of
+        ``height`` rows, of which this rank owns [r0, r1) (see ``shard_rows``). The halo rows
+        feed the Gabor stage with real neighbour data (outer image borders still reflect, as
+        SPEC.md §3 says), are excluded from every k-means sum, and are dropped from the result.
+        Returns the (B, r1-r0, W) int32 labels of the owned rows; identical to the same rows of
+        the unsharded result. Needs torch.distributed initialised when the image is split.
+        """
+        torch = _torch()
+        strip = strip.contiguous()
+        b, hs, w, _ = strip.shape
+        if hs < 8 or w < 8:
+            raise ValueError("strips must be at least 8x8 (including halo)")
+        if not (s0 <= r0 < r1 <= s0 + hs <= height):
+            raise ValueError("inconsistent strip geometry")
+        ws = self._tail_workspace(b, hs, w, "global")
+        self.ops.gabor_features(strip, ws["feats"])
+        k, dfeat = self.k, self.bank.n_features
+        import torch.distributed as td
+        use_dist = td.is_available() and td.is_initialized() and td.get_world_size(dist_group) > 1
+
+        def init(cent):
+            # SPEC.md §4: p_j = floor((2j+1) P / (2k)) over image 0 of the global batch, global coordinates
+            p = height * w
+            byx = []
+            for j in range(k):
+                pj = ((2 * j + 1) * p) // (2 * k)
+                y, x = pj // w, pj % w
+                byx.append((0, y - s0, x) if r0 <= y < r1 else (-1, 0, 0))
+            rows_ = self.ops.features_gather(ws["feats"], b, hs, w,
+                                             torch.tensor(byx, dtype=torch.int32, device=strip.device))
+            table = rows_.view(torch.int16).to(torch.int32) & 0xFFFF          # uint16 values, zero if not owned
+            if use_dist:
+                _collective(td.all_reduce, table, op=td.ReduceOp.SUM, group=dist_group)
+            cent.copy_(table.to(torch.int16).view(1, k, dfeat))               # wraps back to the uint16 bits
+
+        lloyd(self.ops, ws["feats"], b, hs, w, k, self.n_iter, "global", ws["labels"], ws["partials"],
+              ws["cent"], ws["sums"], dist_group, rows=(r0 - s0, r1 - s0), init=init)
+        full = torch.empty((b, hs, w), dtype=torch.int32, device=strip.device)
+        self.ops.labels_widen(ws["labels"], b, hs, w, full)
+        res = full[:, r0 - s0:r1 - s0]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.contiguous()
 
     def features_device(self, imgs):
         """Canonical (B,D,H,W) uint16 features as an int16 tensor (tests / debugging)."""

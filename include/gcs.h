@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 4
+#define GCS_ABI_VERSION 5
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -83,12 +83,19 @@ int gcs_features_unpack(const uint16_t *feats_dev, int B, int H, int W, int D, u
 int gcs_kmeans_init(const uint16_t *feats_dev, int B, int H, int W, int D, int k, int n_sets,
                     uint16_t *centroids_dev, gcs_stream_t stream);
 
+/* Features of n pixels: out_dev[i][0..D) = features of pixel byx_dev[i] = (b, y, x) (int32 triples,
+ * device memory); b < 0 yields a zero row. Used to publish init centroids when one image is
+ * sharded by rows over several ranks (BASELINE config 5). */
+int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int D, int n,
+                        const int32_t *byx_dev, uint16_t *out_dev, gcs_stream_t stream);
+
 /* SPEC.md §4 assign + per-workgroup partial sums (one streaming pass over the slab).
- * labels_dev: label slab; partials_dev: gcs_kmeans_partial_bytes() bytes, fully
- * overwritten (no zeroing needed). */
+ * Only rows [row_lo, row_hi) of each image vote in the sums (whole image: 0, H); halo rows of
+ * a row-sharded image are labelled but do not vote. labels_dev: label slab; partials_dev:
+ * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). */
 int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
-                                 int H, int W, int D, int k, int n_sets, uint8_t *labels_dev,
-                                 uint64_t *partials_dev, gcs_stream_t stream);
+                                 int H, int W, int D, int k, int n_sets, int row_lo, int row_hi,
+                                 uint8_t *labels_dev, uint64_t *partials_dev, gcs_stream_t stream);
 
 /* partials -> sums_dev int64 [n_sets][k][D+1] ([..][D] = count). Deterministic slab
  * reduction (no float, no atomics). In global mode the caller all-reduces sums_dev across

@@ -40,13 +40,24 @@ class OracleOps:
         for s in range(n_sets):
             cent[s] = torch.from_numpy(so.kmeans_init(feats["x"][s], k).astype(np.uint16).view(np.int16))
 
-    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials):
+    def features_gather(self, feats, b, h, w, byx):
+        out = np.zeros((byx.shape[0], self.bank.n_features), np.uint16)
+        for i, (bi, y, x) in enumerate(byx.numpy()):
+            if bi >= 0:
+                out[i] = feats["x"][bi][y * w + x]
+        return torch.from_numpy(out.view(np.int16))
+
+    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None):
         c = cent.numpy().view(np.uint16).astype(np.int64)
+        lo, hi = rows if rows is not None else (0, h)
+        vote = np.zeros((h, w), bool)
+        vote[lo:hi] = True
+        vote = vote.ravel()
         labs, sums = [], np.zeros((n_sets, k, self.bank.n_features + 1), np.int64)
         for i in range(b):
             s = i if n_sets == b else 0
             lab = so.kmeans_assign(feats["x"][i], c[s])
-            _, cnt, sm = so.kmeans_update(feats["x"][i], lab, c[s])
+            _, cnt, sm = so.kmeans_update(feats["x"][i][vote], lab[vote], c[s])
             sums[s, :, :-1] += sm
             sums[s, :, -1] += cnt
             labs.append(lab)
