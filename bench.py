@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU, help="images per GPU")
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--also-other-mode", action="store_true", help="also time the other codebook mode (extra key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -103,11 +104,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device")
+    dev_index = local_rank % n_dev           # one rank per GPU; the modulo only matters for gloo dry runs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     B = args.batch
     imgs_np = synthetic_shard(rank * B, B, H, W, seed=0)      # this rank's shard of the global batch
