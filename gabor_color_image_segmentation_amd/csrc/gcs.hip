@@ -586,8 +586,8 @@ constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-
 #ifndef GCS_KP_WAVES
 #define GCS_KP_WAVES 3
 #endif
-template <int KT, int NST>   // NST = 16-byte staging chunks per thread = ceil(D / 8)
-__global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
+template <int KT, int NST, bool EXACT>   // NST = staging chunks per thread >= ceil(D/8); EXACT: D == 8*NST
+__global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
     int D, int K, int per_image, int parts, int x_first, int x_step, int row_lo, int row_hi,
     uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
@@ -656,19 +656,24 @@ __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass
 
     // ---- staging: the tile is ONE contiguous D*512-byte run of the slab (tile-major layout, already
     //      offset-binary): chunk ci = tid + 256*i is 16 bytes at byte 16*ci -> plane ci>>5, pixels 8*(ci&31)..
+    //      Loads and LDS writes are UNCONDITIONAL: a per-chunk guard makes hipcc branch around every
+    //      load / write with exec masking and drain vmcnt(0) before each write. Chunk rows beyond the
+    //      last plane (D not a multiple of 8, or a coarser NST bucket) are clamped to plane D-1: they
+    //      re-read and re-write row D-1 with its own data.
     const int sd0 = tid >> 5, spo = 8 * (tid & 31);
     v4i st[NST];
-    auto stage_load = [&](int tile) {
-        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * D * KP_TP) + tid;
+    int srow[NST];
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (sd0 + 8 * i < D) st[i] = src[256 * i];
+    for (int i = 0; i < NST; ++i) srow[i] = EXACT ? sd0 + 8 * i : min(sd0 + 8 * i, D - 1);
+    auto stage_load = [&](int tile) {
+        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * D * KP_TP) + (tid & 31);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) st[i] = src[srow[i] * 32];
     };
     auto stage_write = [&]() {
-        unsigned char *dst = &s_tile[sd0 * KP_PITCH + spo * 2];
+        unsigned char *dst = &s_tile[spo * 2];
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (sd0 + 8 * i < D) *reinterpret_cast<v4i *>(dst + (8 * i) * KP_PITCH) = st[i];
+        for (int i = 0; i < NST; ++i) *reinterpret_cast<v4i *>(dst + srow[i] * KP_PITCH) = st[i];
     };
 
     const int un = lane & 15, ug = lane >> 4;             // update operand coordinates
@@ -697,20 +702,48 @@ __global__ __launch_bounds__(256, (KT == 1 ? GCS_KP_WAVES : 2)) void kmeans_pass
             for (int mt = 0; mt < KT; ++mt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][e] = 0;
+            // B fragments by hardware transpose: per 16-lane group ds_read_b64_tr_b16 reads a block of
+            // 4 rows (planes) x 16 columns (pixels) of 16-bit elements and gives lane i column i, i.e.
+            // the four planes of ITS pixel (cdna guide T10). Lane 4q+p of the group supplies the address
+            // of row q, columns 4p..4p+3. Two reads = 8 planes = the 16-byte fragment of one K-step.
+            // (Replaces 8 ds_read_u16 + 4 pack ops per K-step.) One asm statement: loads + their wait.
+            v4i bfr[KP_DSTEPS];
+            {
+                const int i16 = lane & 15, pxblk = (lane >> 4) & 1;
+                const unsigned addr = (unsigned)(size_t)&s_tile[(8 * h + (i16 >> 2)) * KP_PITCH +
+                                                                (wave * 64 + sub * 32 + 16 * pxblk + 4 * (i16 & 3)) * 2];
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                v2i f0a, f0b, f1a, f1b, f2a, f2b, f3a, f3b, f4a, f4b;
+                static_assert(KP_DSTEPS == 5, "five K-steps are read in one asm statement");
+                asm volatile(
+                    "ds_read_b64_tr_b16 %0, %10 offset:%c11\n\t"
+                    "ds_read_b64_tr_b16 %1, %10 offset:%c12\n\t"
+                    "ds_read_b64_tr_b16 %2, %10 offset:%c13\n\t"
+                    "ds_read_b64_tr_b16 %3, %10 offset:%c14\n\t"
+                    "ds_read_b64_tr_b16 %4, %10 offset:%c15\n\t"
+                    "ds_read_b64_tr_b16 %5, %10 offset:%c16\n\t"
+                    "ds_read_b64_tr_b16 %6, %10 offset:%c17\n\t"
+                    "ds_read_b64_tr_b16 %7, %10 offset:%c18\n\t"
+                    "ds_read_b64_tr_b16 %8, %10 offset:%c19\n\t"
+                    "ds_read_b64_tr_b16 %9, %10 offset:%c20\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(f0a), "=&v"(f0b), "=&v"(f1a), "=&v"(f1b), "=&v"(f2a), "=&v"(f2b), "=&v"(f3a), "=&v"(f3b),
+                      "=&v"(f4a), "=&v"(f4b)
+                    : "v"(addr), "i"(0 * KP_PITCH), "i"(4 * KP_PITCH), "i"(16 * KP_PITCH), "i"(20 * KP_PITCH),
+                      "i"(32 * KP_PITCH), "i"(36 * KP_PITCH), "i"(48 * KP_PITCH), "i"(52 * KP_PITCH),
+                      "i"(64 * KP_PITCH), "i"(68 * KP_PITCH)
+                    : "memory");
+                bfr[0] = v4i{f0a[0], f0a[1], f0b[0], f0b[1]};
+                bfr[1] = v4i{f1a[0], f1a[1], f1b[0], f1b[1]};
+                bfr[2] = v4i{f2a[0], f2a[1], f2b[0], f2b[1]};
+                bfr[3] = v4i{f3a[0], f3a[1], f3b[0], f3b[1]};
+                bfr[4] = v4i{f4a[0], f4a[1], f4b[0], f4b[1]};
+            }
 #pragma unroll
-            for (int kk = 0; kk < KP_DSTEPS; ++kk) {
-                const unsigned char *base = &s_tile[(16 * kk + 8 * h) * KP_PITCH + pl * 2];
-                v4i bf;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned lo = *reinterpret_cast<const uint16_t *>(base + (2 * i) * KP_PITCH);
-                    const unsigned hi = *reinterpret_cast<const uint16_t *>(base + (2 * i + 1) * KP_PITCH);
-                    bf[i] = (int)(lo | (hi << 16));
-                }
+            for (int kk = 0; kk < KP_DSTEPS; ++kk)
 #pragma unroll
                 for (int mt = 0; mt < KT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat[mt][kk], bf, acc[mt], 0, 0, 0);
-            }
+                    acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat[mt][kk], bfr[kk], acc[mt], 0, 0, 0);
             long long best = 0x7fffffffffffffffLL;
             int bj = 255;
 #pragma unroll
@@ -841,20 +874,26 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
         const int pstride = (int)gcs_feature_plane_stride(H, W);
         // NOTE: the kernel derives each workgroup's first x from part; x_first is per-part below
 #define GCS_KP_LAUNCH(KT_, NST_)                                                                              \
-    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_>), dim3(parts, B), dim3(256), 0, stream, feats, cent, H, \
+    if (D == 8 * NST_)                                                                                        \
+        GCS_KP_LAUNCH2(KT_, NST_, true);                                                                      \
+    else                                                                                                      \
+        GCS_KP_LAUNCH2(KT_, NST_, false)
+#define GCS_KP_LAUNCH2(KT_, NST_, EX_)                                                                        \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_>), dim3(parts, B), dim3(256), 0, stream, feats, cent, H, \
                        W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, KP_TP % pitch,                         \
                        (int)(((long long)parts * KP_TP) % pitch), row_lo, row_hi, labels, partials)
         const int nst = (D + 7) / 8;
         if (k <= 8) {
-            if (nst <= 3) GCS_KP_LAUNCH(1, 3);
-            else if (nst <= 6) GCS_KP_LAUNCH(1, 6);
-            else if (nst <= 9) GCS_KP_LAUNCH(1, 9);
-            else GCS_KP_LAUNCH(1, 10);
+            if (nst <= 3) { GCS_KP_LAUNCH(1, 3); }
+            else if (nst <= 6) { GCS_KP_LAUNCH(1, 6); }
+            else if (nst <= 9) { GCS_KP_LAUNCH(1, 9); }
+            else { GCS_KP_LAUNCH(1, 10); }
         } else {
-            if (nst <= 9) GCS_KP_LAUNCH(2, 9);
-            else GCS_KP_LAUNCH(2, 10);
+            if (nst <= 9) { GCS_KP_LAUNCH(2, 9); }
+            else { GCS_KP_LAUNCH(2, 10); }
         }
 #undef GCS_KP_LAUNCH
+#undef GCS_KP_LAUNCH2
         GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
         return GCS_OK;
     }

@@ -1,6 +1,7 @@
 // Read-only HBM streaming ceiling on MI355X for k-means-like access: 1.43 GB per launch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // variant A: grid-stride, every thread keeps U independent 16-byte loads in flight, no LDS, no barrier
@@ -73,6 +74,14 @@ int main() {
     v4i *src; int *out;
     hipMalloc(&src, bytes); hipMalloc(&out, 4);
     hipMemset(src, 1, bytes);
+    if (getenv("RANDOM_FILL")) {   // same traffic, random payload (HBM / fabric power is data dependent)
+        unsigned *h = (unsigned *)malloc(bytes);
+        unsigned x = 12345u;
+        for (size_t i = 0; i < bytes / 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = x; }
+        hipMemcpy(src, h, bytes, hipMemcpyHostToDevice);
+        free(h);
+        printf("random fill\n");
+    }
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     auto time = [&](auto launch, const char *name) {
         launch(); hipDeviceSynchronize();
