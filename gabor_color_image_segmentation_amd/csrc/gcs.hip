@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void gabor_pad_kernel(const uint8_t *__restric
 #ifndef GCS_GABOR_MTMAX
 #define GCS_GABOR_MTMAX 2
 #endif
-template <int MT>
+template <int MT, bool FULLF>   // FULLF: n_filters is a multiple of 8 -> no per-filter store guard
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int H, int Hp, int Wp, const int8_t *__restrict__ apack,
     const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats, int pitch,
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int f = 8 * (mt0 + mt) + 2 * g + h;
-                        if (f < F) {
+                        if (FULLF || f < F) {
                             // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
                             // signed MFMA digits for the k-means pass, which stages them untouched
                             uint16_t *dst = feats + slab_index((size_t)b * (pstride >> 8), D, c * F + f, oy * pitch + ox);
@@ -356,15 +356,14 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     const int MT = mtiles(F);
     for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
         const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
-        if (n == 3)
-            hipLaunchKernelGGL(gabor_mfma_kernel<3>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, pstride, tiles_x);
-        else if (n == 2)
-            hipLaunchKernelGGL(gabor_mfma_kernel<2>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, pstride, tiles_x);
-        else
-            hipLaunchKernelGGL(gabor_mfma_kernel<1>, grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0,
-                               F, shift, feats, pitch, pstride, tiles_x);
+#define GCS_GABOR_LAUNCH(MT_, FF_)                                                                              \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, FF_>), grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0, \
+                       F, shift, feats, pitch, pstride, tiles_x)
+        const bool fullf = (F % 8) == 0;
+        if (n == 3) { if (fullf) GCS_GABOR_LAUNCH(3, true); else GCS_GABOR_LAUNCH(3, false); }
+        else if (n == 2) { if (fullf) GCS_GABOR_LAUNCH(2, true); else GCS_GABOR_LAUNCH(2, false); }
+        else { if (fullf) GCS_GABOR_LAUNCH(1, true); else GCS_GABOR_LAUNCH(1, false); }
+#undef GCS_GABOR_LAUNCH
         GCS_CHECK_LAUNCH("gcs_gabor_features");
     }
     return GCS_OK;
@@ -983,5 +982,103 @@ extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int3
     hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, stream, labels, H, W, (int)gcs_feature_pitch(W),
                        gcs_feature_plane_stride(H, W), (size_t)B * H * W, out);
     GCS_CHECK_LAUNCH("gcs_labels_widen");
+    return GCS_OK;
+}
+
+// ======================================================================= boundary scoring (§8f-1)
+// Integer restatement of /root/reference/BSD_metrics/metrics.py:25-51,58-96 for ONE image:
+//   bd(M)   = thick boundaries of an integer map M: max != min over the 3x3 cross (find_boundaries
+//             defaults; reflect border == clamped indices for max/min filters)
+//   dil5(b) = 5x5 binary dilation (dilation(., rectangle(5,5)); same border argument)
+// counts[0] = sum bd(L);  per annotator a: counts[1+3a] = sum dil5(bd(L)) & bd(T_a)   (recall numerator)
+//                                           counts[2+3a] = sum bd(T_a)                 (recall denominator)
+//                                           counts[3+3a] = sum bd(L) & dil5(bd(T_a))   (precision numerator)
+// The float divisions and the per-annotator mean stay on the host, in the reference's order.
+template <typename T>
+__device__ __forceinline__ bool thick_boundary(const T *m, int H, int W, int y, int x) {
+    const T c = m[(size_t)y * W + x];
+    const T u = m[(size_t)max(y - 1, 0) * W + x], d = m[(size_t)min(y + 1, H - 1) * W + x];
+    const T l = m[(size_t)y * W + max(x - 1, 0)], r = m[(size_t)y * W + min(x + 1, W - 1)];
+    return u != c || d != c || l != c || r != c;   // max != min over {c,u,d,l,r}
+}
+
+// maps: plane 0 = boundaries of the label map, planes 1..A = boundaries of the annotator maps
+__global__ void boundary_maps_kernel(const int32_t *__restrict__ labels, const uint16_t *__restrict__ truth, int A,
+                                     int H, int W, uint8_t *__restrict__ maps) {
+    const int n = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (A + 1) * n; i += gridDim.x * blockDim.x) {
+        const int a = i / n, p = i % n, y = p / W, x = p % W;
+        maps[i] = a == 0 ? thick_boundary(labels, H, W, y, x)
+                         : thick_boundary(truth + (size_t)(a - 1) * n, H, W, y, x);
+    }
+}
+
+__device__ __forceinline__ bool dilated5(const uint8_t *b, int H, int W, int y, int x) {
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if (xx >= 0 && xx < W && b[(size_t)yy * W + xx]) return true;
+        }
+    }
+    return false;
+}
+
+__global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, int A, int H, int W,
+                                       unsigned long long *__restrict__ counts) {
+    const int n = H * W;
+    const int a = blockIdx.y;                         // 0: label-only count, 1..A: annotator a-1
+    unsigned c0 = 0, c1 = 0, c2 = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p % W;
+        const bool bl = maps[p];
+        if (a == 0) {
+            c0 += bl;
+        } else {
+            const uint8_t *tb = maps + (size_t)a * n;
+            const bool bt = tb[p];
+            c0 += bt && dilated5(maps, H, W, y, x);  // recall numerator
+            c1 += bt;                                  // recall denominator
+            c2 += bl && dilated5(tb, H, W, y, x);    // precision numerator
+        }
+    }
+    // wave reduction, one atomic per wave (integers: order-independent)
+    for (int m = 32; m >= 1; m >>= 1) {
+        c0 += __shfl_xor(c0, m);
+        c1 += __shfl_xor(c1, m);
+        c2 += __shfl_xor(c2, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a == 0) {
+            atomicAdd(&counts[0], (unsigned long long)c0);
+        } else {
+            atomicAdd(&counts[1 + 3 * (a - 1)], (unsigned long long)c0);
+            atomicAdd(&counts[2 + 3 * (a - 1)], (unsigned long long)c1);
+            atomicAdd(&counts[3 + 3 * (a - 1)], (unsigned long long)c2);
+        }
+    }
+}
+
+extern "C" size_t gcs_boundary_scratch_bytes(int A, int H, int W) {
+    if (A <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)(A + 1) * H * W;
+}
+
+extern "C" int gcs_boundary_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, void *scratch,
+                                   uint64_t *counts, gcs_stream_t stream) {
+    if (!labels || !truth || !scratch || !counts) return fail(GCS_EINVAL, "gcs_boundary_counts: NULL pointer");
+    if (A <= 0 || A > 65535 || H <= 0 || W <= 0 || (long long)H * W * (A + 1) > 0x7fffffffLL)
+        return fail(GCS_EINVAL, "gcs_boundary_counts: bad shape");
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(1 + 3 * A) * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return hip_fail(e, "gcs_boundary_counts(memset)");
+    uint8_t *maps = static_cast<uint8_t *>(scratch);
+    const int n = H * W;
+    hipLaunchKernelGGL(boundary_maps_kernel, dim3(min(2048, ((A + 1) * n + 255) / 256)), dim3(256), 0, stream, labels,
+                       truth, A, H, W, maps);
+    GCS_CHECK_LAUNCH("gcs_boundary_counts(maps)");
+    hipLaunchKernelGGL(boundary_counts_kernel, dim3(min(256, (n + 255) / 256), A + 1), dim3(256), 0, stream, maps, A, H,
+                       W, reinterpret_cast<unsigned long long *>(counts));
+    GCS_CHECK_LAUNCH("gcs_boundary_counts");
     return GCS_OK;
 }

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 5
+#define GCS_ABI_VERSION 6
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -110,6 +110,19 @@ int gcs_kmeans_finalize(const int64_t *sums_dev, int n_sets, int k, int D,
 /* Label slab -> int32 [B][H][W] (the dtype handed to metrics.py:43). */
 int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *out_dev,
                      gcs_stream_t stream);
+
+/* ---- boundary scoring of one image -------------------------------------- */
+
+/* Integer part of /root/reference/BSD_metrics/metrics.py:25-51 (thick find_boundaries of the label
+ * map and of each annotator map), :58-74 (recall) and :77-96 (precision): labels_dev int32 [H][W],
+ * truth_dev uint16 [A][H][W] (the `Segmentation` arrays groundtruth.py:22-26 returns). Writes
+ * counts_dev uint64 [1 + 3A]: [0] = #boundary pixels of the label map (metrics.py:90); for
+ * annotator a: [1+3a] = sum(dilate5(bd(labels)) & bd(T_a)) and [2+3a] = sum(bd(T_a)) (metrics.py:69-72),
+ * [3+3a] = sum(bd(labels) & dilate5(bd(T_a))) (metrics.py:93-94). The caller divides and averages in
+ * the reference's order. scratch_dev: gcs_boundary_scratch_bytes() bytes. */
+size_t gcs_boundary_scratch_bytes(int A, int H, int W);
+int gcs_boundary_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
+                        void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,22 @@ def test_find_boundaries_is_thick_and_ignores_the_image_border():
     lab[:, 3:] = 1
     b = find_boundaries(lab)
     assert b[:, 2].all() and b[:, 3].all() and b.sum() == 12
+
+
+def test_packed_groundtruth_reader():
+    from gabor_color_image_segmentation_amd.groundtruth import load_packed
+    data = load_packed(os.path.join(GOLD, "bsd_inputs.npz"))
+    assert sorted(data) == ["100075", "100080", "100098"]
+    img, segs = data["100080"]
+    assert img.shape == (481, 321, 3) and img.dtype == np.uint8 and len(segs) == int(INP["nseg_100080"])
+    assert all(s.shape == (481, 321) for s in segs)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/BSD_metrics/data/truth"), reason="reference data not mounted")
+def test_mat_loader_mirror_matches_the_fixture():
+    """groundtruth.get_segment_from_filename mirror on the reference's own .mat files (this container only)."""
+    from gabor_color_image_segmentation_amd.groundtruth import get_segment_from_filename
+    segs = get_segment_from_filename("100080", path="/root/reference/BSD_metrics/data/truth/")
+    assert len(segs) == int(INP["nseg_100080"])
+    for a, s in enumerate(segs):
+        assert np.array_equal(s, INP["seg_100080_%d" % a])
