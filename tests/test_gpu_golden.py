@@ -121,3 +121,22 @@ def test_degenerate_inputs(seg):
     assert np.array_equal(seg(img), np.zeros((32, 48), np.int32))
     with pytest.raises(ValueError):
         seg(np.zeros((7, 40, 3), np.uint8))
+
+
+def test_integration_md_ctypes_stub_runs_and_matches_the_oracle(built):
+    """The binding shown to a maintainer in INTEGRATION.md is executed verbatim."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C.*?)```", text, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                       # the stub loads the library by its repo-relative path
+    try:
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+        from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+        img = synthetic_batch(1, 56, 88, seed=17)[0]
+        got = ns["segment"](img, k=6, n_iter=4)
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(got, so.segment(img, k=6, n_iter=4))
