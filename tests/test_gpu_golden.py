@@ -140,3 +140,14 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_oracle(built):
     finally:
         os.chdir(cwd)
     assert np.array_equal(got, so.segment(img, k=6, n_iter=4))
+
+
+def test_sixty_four_filter_bank_full_segment(built):
+    """BASELINE config 4 end to end (D = 192: four Gabor launches, generic k-means pass)."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(2, 40, 64, seed=23)
+    s = Segmenter(n_scales=8, n_orient=8, k=6, n_iter=3)
+    got = s.segment_batch(imgs, mode="global")
+    tapq, shift = so.bank(8, 8)
+    assert np.array_equal(got, co.segment_batch(imgs, tapq, shift, k=6, n_iter=3, mode="global"))
