@@ -758,8 +758,15 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
                         bj = j;
                     }
                 }
-            const long long pb = __shfl_xor(best, 32);
-            const int pj = __shfl_xor(bj, 32);
+            // partner half's (score, index) by v_permlane32_swap (VALU; no LDS round trip like ds_bpermute)
+            const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
+            const auto s2 = __builtin_amdgcn_permlane32_swap((unsigned)bj, (unsigned)bj, false, false);
+            // after swap(x, x): element 1 holds the upper half's x in lanes 0-31, element 0 the lower half's x in lanes 32-63
+            const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1[0] : s1[1];
+            const int pj = (int)(h ? s2[0] : s2[1]);
+            const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
             if (pb < best || (pb == best && pj < bj)) bj = pj;
             if (h == 0) {
                 const int pp = pp0 + pl;
