@@ -86,3 +86,33 @@ def test_row_sharded_image_on_gpu_two_ranks(tmp_path):
     tapq, shift = so.bank()
     ref = co.segment_batch(synthetic_batch(b, height, width, seed=13), tapq, shift, k=8, n_iter=5, mode="global")
     assert np.array_equal(got, ref)
+
+
+def _big_strip_worker(rank, world, port, height, width, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gabor_color_image_segmentation_amd import Segmenter, shard_rows
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(1, height, width, seed=41)
+    r0, r1, s0, s1 = shard_rows(height, world, rank)
+    seg = Segmenter(n_iter=4, device="cuda:0")
+    out = seg.segment_rows_sharded_device(torch.from_numpy(np.ascontiguousarray(imgs[:, s0:s1])).cuda(), r0, r1, s0, height)
+    np.save(os.path.join(tmp, f"big_{rank}.npy"), out.cpu().numpy().astype(np.uint8))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config5_size_2048_sharded_equals_unsharded_on_gpu(tmp_path):
+    """BASELINE config 5's real tile size: one 2048x2048 image, 2 row strips with halo == the unsharded GPU result
+    (the unsharded path itself is pinned to the oracle at smaller sizes)."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    height = width = 2048
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_big_strip_worker, args=(2, port, height, width, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / f"big_{r}.npy") for r in range(2)], axis=1)
+    ref = Segmenter(n_iter=4).segment_batch(synthetic_batch(1, height, width, seed=41), mode="global")
+    assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.uint8))
+    assert len(np.unique(ref)) > 1
