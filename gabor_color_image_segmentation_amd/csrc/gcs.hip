@@ -154,14 +154,20 @@ __device__ __forceinline__ int reflect_clamp(int i, int n) {
     return min(max(i, 0), n - 1); // only reached for pixels whose outputs are not stored
 }
 
-// floor(sqrt(n)) for n < 2^31, exact: v_sqrt_f32 (1 ulp) biased low by (1-2^-20) lands in
-// {floor-1, floor}; one integer test fixes it (SPEC.md §3).
+// floor(sqrt(n)) for n <= 2 * 32642^2 < 2^31 (SPEC.md §3 bound), exact, in 8 cheap VALU ops
+// (measured on gfx950, tools/ubench/valu_ops2: v_cvt_u32_f32 ~3 ns and v_cmp+v_addc ~4.3 ns per
+// wave-instruction, against ~1.2 ns for an add):
+//   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
+//   bits = r + 2^23 (as uint)          the sum has ulp 1: bits = 0x4B000000 + RNE(r), RNE(r) in {floor(s), floor(s)+1}
+//   qr^2 = v_mul_u32_u24(bits, bits)   the multiplier only sees the low 24 bits, i.e. qr = RNE(r) (< 2^16)
+//   q    = qr - (qr^2 > n)             sign arithmetic, one v_add3: bits - 0x4B000000 + ((int)(n - qr^2) >> 31);
+//                                      qr <= 46164 so qr^2 < 2^31 and the signed difference cannot overflow.
+// 7 VALU instructions; in this kernel every VALU instruction costs ~4.2 cycles whatever its kind (PMC),
+// so the count is what matters.
 __device__ __forceinline__ unsigned isqrt31(unsigned n) {
-    const float r = __builtin_amdgcn_sqrtf((float)n) * 0.99999905f;
-    unsigned q = (unsigned)r;
-    const unsigned q1 = q + 1u;
-    q += (__umul24(q1, q1) <= n) ? 1u : 0u;
-    return q;
+    const unsigned bits = __float_as_uint(__builtin_amdgcn_sqrtf((float)n) + 8388608.0f);
+    const int d = (int)(n - __umul24(bits, bits));
+    return bits - 0x4B000000u + (unsigned)(d >> 31);
 }
 
 // Pre-pass: interleaved uint8 RGB -> planar (pixel - 128) int8 with the reflect border and
@@ -198,25 +204,39 @@ template <int MT, bool FULLF>   // FULLF: n_filters is a multiple of 8 -> no per
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int H, int Hp, int Wp, const int8_t *__restrict__ apack,
     const int32_t *__restrict__ bias, int mt0, int F, int shift, uint16_t *__restrict__ feats, int pitch,
-    size_t pstride, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) int8_t s_tile[3][G_LROWS][G_LPITCH];
+    size_t pstride, int tiles_x, int tiles_per_image, int total_tiles) {
+    // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
+    // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
+    // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
+    // 846 16-byte chunks, i.e. exactly the lane-linear destination LDS-DMA wants.
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][3][G_LROWS][G_LPITCH];
+    constexpr int NCHUNK = 3 * G_LROWS * (G_LPITCH / 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-    const int y0 = ty * G_TH, x0 = tx * G_TW;
     const int D = 3 * F;
 
-    // ---- stage the 3-channel tile: 3 x 47 rows x 6 aligned 16-byte chunks
-    for (int i = tid; i < 3 * G_LROWS * (G_LPITCH / 16); i += 256) {
-        const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
-        const int row = rc % G_LROWS, c = rc / G_LROWS;
-        const v4i v = *reinterpret_cast<const v4i *>(planes + (((size_t)b * 3 + c) * Hp + y0 + row) * Wp + x0 +
-                                                     16 * ch16);
-        *reinterpret_cast<v4i *>(&s_tile[c][row][16 * ch16]) = v;
-    }
+    auto stage_tile = [&](int tile, int buf) {
+        const int b_ = tile / tiles_per_image, rem = tile % tiles_per_image;
+        const int y0_ = (rem / tiles_x) * G_TH, x0_ = (rem % tiles_x) * G_TW;
+        const int8_t *src0 = planes + ((size_t)b_ * 3 * Hp + y0_) * Wp + x0_;
+#pragma unroll
+        for (int k = 0; k < (NCHUNK + 255) / 256; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NCHUNK) {
+                const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
+                const int row = rc % G_LROWS, c = rc / G_LROWS;
+                const int8_t *g = src0 + ((size_t)c * Hp + row) * Wp + 16 * ch16;
+                // LDS destination: wave-uniform base (this wave's first chunk) + lane * 16
+                int8_t *l = &s_tile[buf][0][0][0] + 16 * (256 * k + 64 * wave);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)g,
+                    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+            }
+        }
+    };
+
     // ---- the whole A operand lives in registers: MT x 8 lane-linear 16-byte fragments
     v4i afr[MT][8];
 #pragma unroll
@@ -224,14 +244,12 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
             afr[mt][kk] = reinterpret_cast<const v4i *>(apack)[((size_t)(mt0 + mt) * 8 + kk) * 64 + lane];
-    __syncthreads();
 
     // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
     // for a pixel shift s = 4*qq + t in 0..7. A lane therefore ends up owning 8 consecutive
     // pixels (16 bytes) per filter and a store instruction writes whole 128-byte lines.
     const int r = lane & 31, h = lane >> 5;
     const int li = r & 7, lyy = r >> 3;
-    if (y0 + wave * 8 >= H) return;     // whole wave outside the image (no barrier follows)
 
     int bias_v[MT][4];
 #pragma unroll
@@ -239,6 +257,15 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias_v[mt][g] = bias[8 * (mt0 + mt) + 2 * g + h];
 
+    int tile = blockIdx.x;
+    if (tile < total_tiles) stage_tile(tile, 0);
+    __syncthreads();                       // drains the LDS-DMA (vmcnt) and orders it for every wave
+    for (int it = 0; tile < total_tiles; tile += gridDim.x, ++it) {
+      const int buf = it & 1;
+      if (tile + (int)gridDim.x < total_tiles) stage_tile(tile + gridDim.x, buf ^ 1);
+      const int b = tile / tiles_per_image, trem = tile % tiles_per_image;
+      const int y0 = (trem / tiles_x) * G_TH, x0 = (trem % tiles_x) * G_TW;
+      if (y0 + wave * 8 < H) {            // waves wholly below the image skip the work, not the barrier
     for (int c = 0; c < 3; ++c) {
 #pragma unroll 1
         for (int rb = 0; rb < 2; ++rb) {       // two 4-row blocks per wave
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                 int win[8][5];
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    const int *rp = reinterpret_cast<const int *>(&s_tile[c][trow + 2 * kk + h][8 * li + 4 * qq]);
+                    const int *rp = reinterpret_cast<const int *>(&s_tile[buf][c][trow + 2 * kk + h][8 * li + 4 * qq]);
 #pragma unroll
                     for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
                 }
@@ -267,9 +294,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                         v4i bf;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            bf[j] = (t == 0) ? win[kk][j]
-                                             : (int)__builtin_amdgcn_alignbyte((unsigned)win[kk][j + 1],
-                                                                               (unsigned)win[kk][j], t);
+                            bf[j] = (t == 0) ? win[kk][j]       // v_alignbit_b32: same result as v_alignbyte, 2.4x the rate
+                                             : (int)__builtin_amdgcn_alignbit((unsigned)win[kk][j + 1],
+                                                                              (unsigned)win[kk][j], 8 * t);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
@@ -281,8 +308,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int a_re = ((acc[mt][4 * g + 1] << 8) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
-                            const int a_im = ((acc[mt][4 * g + 3] << 8) + acc[mt][4 * g + 2]) >> shift;
+                            // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22), not a shift (slow here)
+                            const int a_re = (__mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
+                            const int a_im = (__mul24(acc[mt][4 * g + 3], 256) + acc[mt][4 * g + 2]) >> shift;
                             const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
                             mag[mt][g] = isqrt31(n);
                         }
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                             if ((t & 1) == 0)
                                 o = mag[mt][g];
                             else
-                                o |= mag[mt][g] << 16;
+                                o = __umul24(mag[mt][g], 65536u) + o;      // pack the odd pixel into the high half
                             // materialise now: otherwise hipcc sinks the whole epilogue into the
                             // store branches and keeps every accumulator live until then
                             asm volatile("" : "+v"(o));
@@ -324,6 +352,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             }
         }
     }
+      }
+      __syncthreads();   // next tile landed (vmcnt drained) and this buffer is free to refill
+    }
 }
 
 static inline int gabor_hp(int H) { return (H + G_TH - 1) / G_TH * G_TH + 15; }
@@ -352,13 +383,20 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     hipLaunchKernelGGL(gabor_pad_kernel, dim3((Wp / 4 + 255) / 256, Hp, B), dim3(256), 0, stream, img, H, W, Hp, Wp,
                        planes);
     GCS_CHECK_LAUNCH("gcs_gabor_features(pad)");
-    const dim3 grid(tiles_x * tiles_y, B), block(256);
+    const int tiles_per_image = tiles_x * tiles_y;
+    const long long total_ll = (long long)tiles_per_image * B;
+    if (total_ll > 0x7fffffffLL) return fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
+    const int total_tiles = (int)total_ll;
+    const dim3 block(256);
     const int MT = mtiles(F);
     for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
         const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
+        // persistent grid: one workgroup per resident slot (2 per CU at MT >= 2, 3 at MT == 1)
+        const int slots = 256 * (n == 1 ? 3 : 2);
+        const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH(MT_, FF_)                                                                              \
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, FF_>), grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0, \
-                       F, shift, feats, pitch, pstride, tiles_x)
+                       F, shift, feats, pitch, pstride, tiles_x, tiles_per_image, total_tiles)
         const bool fullf = (F % 8) == 0;
         if (n == 3) { if (fullf) GCS_GABOR_LAUNCH(3, true); else GCS_GABOR_LAUNCH(3, false); }
         else if (n == 2) { if (fullf) GCS_GABOR_LAUNCH(2, true); else GCS_GABOR_LAUNCH(2, false); }
