@@ -639,22 +639,30 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
     const int ntiles = pstride / KP_TP;              // plane stride is a whole number of tiles
     const uint16_t *fb = feats + (size_t)b * ntiles * D * KP_TP;   // this image's tiles, each D*256 contiguous
 
-    // ---- per-cluster constant: |c|^2 - 2*(offset terms of the -128 digits), exact int64
-    if (tid < 16) {
-        long long cst = 0;
-        if (tid < K) {
-            long long nrm = 0, scl = 0, sch = 0;
-            for (int d = 0; d < D; ++d) {
-                const long long c = cset[tid * D + d];
+    // ---- per-cluster key base (exact int64): 16 * (|c|^2 - 2*(offset terms of the -128 digits)) + j.
+    //      key_j = base_j - 32 R0 - 8192 R1 - 2^21 R2 = 16 * score_j + j, so ONE 64-bit minimum yields the
+    //      best score and the lowest index on ties. 16 lanes per cluster, folded with lane shuffles.
+    {
+        const int j = tid >> 4, sub = tid & 15;
+        long long nrm = 0, scl = 0, sch = 0;
+        if (j < K)
+            for (int d = sub; d < D; d += 16) {
+                const long long c = cset[j * D + d];
                 nrm += c * c;
                 scl += c & 255;
                 sch += c >> 8;
             }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            nrm += __shfl_xor(nrm, m);
+            scl += __shfl_xor(scl, m);
+            sch += __shfl_xor(sch, m);
+        }
+        if (sub == 0) {
             const long long q = 16384LL * D;
             const long long g = (128 * scl - q) + 256 * (128 * (sch + scl) - 2 * q) + 65536 * (128 * sch - q);
-            cst = nrm - 2 * g;
+            s_const[j] = j < K ? 16 * (nrm - 2 * g) + j : (1LL << 62) + j;
         }
-        s_const[tid] = cst;
     }
     // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
     if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
@@ -781,31 +789,26 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
 #pragma unroll
                 for (int mt = 0; mt < KT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat[mt][kk], bfr[kk], acc[mt], 0, 0, 0);
+            // key = 16*score + j via v_mad_i64_i32 (3 instructions per cluster instead of ~25 of sign
+            // extension / 64-bit shift / borrow arithmetic): U = R0 + 256 R1 fits int32 (|U| < 2^30).
             long long best = 0x7fffffffffffffffLL;
-            int bj = 255;
 #pragma unroll
             for (int mt = 0; mt < KT; ++mt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int j = 8 * mt + 2 * g + h;
-                    const long long t = (long long)acc[mt][4 * g] + ((long long)acc[mt][4 * g + 1] << 8) +
-                                        ((long long)acc[mt][4 * g + 2] << 16);
-                    const long long sc = s_const[j] - 2 * t;
-                    if (j < K && sc < best) {
-                        best = sc;
-                        bj = j;
-                    }
+                    const int u = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g];
+                    long long key = (long long)u * -32 + s_const[8 * mt + 2 * g + h];   // LDS broadcast read
+                    key = (long long)acc[mt][4 * g + 2] * -2097152 + key;
+                    best = key < best ? key : best;
                 }
-            // partner half's (score, index) by v_permlane32_swap (VALU; no LDS round trip like ds_bpermute)
+            // partner half's key by v_permlane32_swap (VALU; no LDS round trip like ds_bpermute)
             const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
             const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
-            const auto s2 = __builtin_amdgcn_permlane32_swap((unsigned)bj, (unsigned)bj, false, false);
             // after swap(x, x): element 1 holds the upper half's x in lanes 0-31, element 0 the lower half's x in lanes 32-63
             const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1[0] : s1[1];
-            const int pj = (int)(h ? s2[0] : s2[1]);
             const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
-            if (pb < best || (pb == best && pj < bj)) bj = pj;
+            const int bj = (int)((pb < best ? pb : best) & 15);
             if (h == 0) {
                 const int pp = pp0 + pl;
                 int x = x0 + pl;                     // pixel column: at most ceil(256/pitch)+1 wraps
