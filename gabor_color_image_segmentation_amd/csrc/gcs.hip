@@ -614,6 +614,14 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
 //            one spare byte-plane is all ones and yields the counts. Accumulators live in
 //            registers for the whole workgroup; nothing but the tile load touches HBM.
 // The one-hot digit is 0x80 (= -128) to save a shift; it is divided out exactly at the end.
+// D = a * b + c with a 64-bit accumulator in ONE instruction. hipcc strength-reduces the C expression
+// into sign extensions, 64-bit shifts and borrow chains (~10 instructions); the count is what costs here.
+__device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
+    long long d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
+    return d;
+}
+
 constexpr int KP_TP = 256;                // pixels per tile: 4 waves x 64
 constexpr int KP_ROWS = 80;               // plane rows held in LDS
 constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
@@ -797,8 +805,8 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int u = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g];
-                    long long key = (long long)u * -32 + s_const[8 * mt + 2 * g + h];   // LDS broadcast read
-                    key = (long long)acc[mt][4 * g + 2] * -2097152 + key;
+                    long long key = mad_i64_i32(u, -32, s_const[8 * mt + 2 * g + h]);   // base: LDS broadcast read
+                    key = mad_i64_i32(acc[mt][4 * g + 2], -2097152, key);
                     best = key < best ? key : best;
                 }
             // partner half's key by v_permlane32_swap (VALU; no LDS round trip like ds_bpermute)
