@@ -1138,3 +1138,110 @@ extern "C" int gcs_boundary_counts(const int32_t *labels, const uint16_t *truth,
     GCS_CHECK_LAUNCH("gcs_boundary_counts");
     return GCS_OK;
 }
+
+// ================================================================== connected regions (§8f-4)
+// SPEC.md §7: 4-connected components of equal labels, renumbered 0,1,2,... in raster order of each
+// component's first pixel (so "Regions" = max+1 at /root/reference/BSD_metrics/metrics.py:51 counts
+// connected regions, as it does for the SLIC output the slot holds today). Lock-free union-find:
+// parents only ever decrease (atomicMin), a root is the smallest pixel index of its component, and a
+// failed link (someone re-parented the node meanwhile) retries from the displaced parent, so no
+// equivalence is lost even when a find reads a stale pointer.
+__device__ __forceinline__ int cc_find(const int *parent, int x) {
+    for (;;) {
+        const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
+
+__device__ __forceinline__ void cc_unite(int *parent, int a, int b) {
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // link the larger root under the smaller
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;                                          // a was re-parented meanwhile: merge that chain too
+    }
+}
+
+__global__ void cc_union_kernel(const int32_t *__restrict__ labels, int H, int W, int *__restrict__ parent) {
+    const int P = H * W;
+    const int32_t *lab = labels + (size_t)blockIdx.y * P;
+    int *par = parent + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p % W;
+        const int32_t l = lab[p];
+        if (x + 1 < W && lab[p + 1] == l) cc_unite(par, p, p + 1);
+        if (y + 1 < H && lab[p + W] == l) cc_unite(par, p, p + W);
+    }
+}
+
+__global__ void cc_local_init_kernel(int H, int W, int *__restrict__ parent) {
+    const int P = H * W;
+    int *par = parent + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) par[p] = p;
+}
+
+// one workgroup per image: flatten, count roots per contiguous chunk, scan, hand out ids in raster order
+__global__ __launch_bounds__(1024) void cc_rank_kernel(int H, int W, int *__restrict__ parent, int *__restrict__ rootid) {
+    __shared__ int s_cnt[1024];
+    const int P = H * W;
+    int *par = parent + (size_t)blockIdx.x * P;
+    int *rid = rootid + (size_t)blockIdx.x * P;
+    const int tid = threadIdx.x;
+    const int chunk = (P + 1023) / 1024;
+    const int lo = min(P, tid * chunk), hi = min(P, lo + chunk);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += par[p] == p;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int id = s_cnt[tid] - cnt;                           // exclusive prefix = first id of this chunk
+    for (int p = lo; p < hi; ++p)
+        if (par[p] == p) rid[p] = id++;
+}
+
+__global__ void cc_relabel_kernel(int H, int W, const int *__restrict__ parent, const int *__restrict__ rootid,
+                                  int32_t *__restrict__ out) {
+    const int P = H * W;
+    const int *par = parent + (size_t)blockIdx.y * P;
+    const int *rid = rootid + (size_t)blockIdx.y * P;
+    int32_t *o = out + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int r = par[p];
+        while (par[r] != r) r = par[r];                  // the union kernel has finished: plain loads are current
+        o[p] = rid[r];
+    }
+}
+
+extern "C" size_t gcs_connected_scratch_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)2 * B * H * W * sizeof(int32_t);
+}
+
+extern "C" int gcs_connected_regions(const int32_t *labels, int B, int H, int W, void *scratch, int32_t *out,
+                                     gcs_stream_t stream) {
+    if (!labels || !scratch || !out) return fail(GCS_EINVAL, "gcs_connected_regions: NULL pointer");
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return fail(GCS_EINVAL, "gcs_connected_regions: bad shape");
+    const int P = H * W;
+    int *parent = static_cast<int *>(scratch);
+    int *rootid = parent + (size_t)B * P;
+    const dim3 grid(min(1024, (P + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(cc_local_init_kernel, grid, block, 0, stream, H, W, parent);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(init)");
+    hipLaunchKernelGGL(cc_union_kernel, grid, block, 0, stream, labels, H, W, parent);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(union)");
+    hipLaunchKernelGGL(cc_rank_kernel, dim3(B), dim3(1024), 0, stream, H, W, parent, rootid);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(rank)");
+    hipLaunchKernelGGL(cc_relabel_kernel, grid, block, 0, stream, H, W, parent, rootid, out);
+    GCS_CHECK_LAUNCH("gcs_connected_regions");
+    return GCS_OK;
+}

@@ -110,6 +110,13 @@ class HipOps:
         _lib.check(self.lib.gcs_kmeans_finalize(sums.data_ptr(), n_sets, k, self.bank.n_features,
                                                 cent.data_ptr(), self._stream()), "gcs_kmeans_finalize")
 
+    def connected_regions(self, labels_i32, out):
+        """SPEC.md §7 on an int32 (B,H,W) device tensor."""
+        b, h, w = labels_i32.shape
+        scratch = self.empty_bytes(self.lib.gcs_connected_scratch_bytes(b, h, w))
+        _lib.check(self.lib.gcs_connected_regions(labels_i32.data_ptr(), b, h, w, scratch.data_ptr(),
+                                                  out.data_ptr(), self._stream()), "gcs_connected_regions")
+
     def labels_widen(self, labels, b, h, w, out):
         _lib.check(self.lib.gcs_labels_widen(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
                    "gcs_labels_widen")
@@ -180,12 +187,13 @@ class Segmenter:
     """Reusable plan: bank on device + cached workspaces. ``__call__`` is the slot."""
 
     def __init__(self, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=15, f_max=0.4,
-                 ratio=math.sqrt(2.0), bandwidth=1.0, device="cuda:0", ops=None):
+                 ratio=math.sqrt(2.0), bandwidth=1.0, connectivity=False, device="cuda:0", ops=None):
         if not (1 <= k <= _lib.K_MAX):
             raise ValueError(f"k must be in 1..{_lib.K_MAX}")
         if n_iter < 1:
             raise ValueError("n_iter must be >= 1")
         self.k, self.n_iter = int(k), int(n_iter)
+        self.connectivity = bool(connectivity)     # SPEC.md §7 post-pass
         self.bank = make_bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
         self.ops = ops if ops is not None else HipOps(self.bank, device)
         self._ws = {}
@@ -231,6 +239,10 @@ class Segmenter:
             lloyd(self.ops, ws["feats"], n, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
                   ws["cent"], ws["sums"], dist_group)
             self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
+        if self.connectivity:
+            regions = torch.empty_like(out)
+            self.ops.connected_regions(out, regions)
+            out.copy_(regions)
         return out
 
     def _tail_workspace(self, n, h, w, mode):

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 6
+#define GCS_ABI_VERSION 7
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -123,6 +123,16 @@ int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *ou
 size_t gcs_boundary_scratch_bytes(int A, int H, int W);
 int gcs_boundary_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
                         void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
+
+/* ---- connected regions (SPEC.md §7) -------------------------------------- */
+
+/* labels_dev int32 [B][H][W] -> out_dev int32 [B][H][W]: 4-connected components of equal labels,
+ * renumbered 0,1,2,... in raster order of each component's first pixel, per image. Makes
+ * `Regions = max + 1` (/root/reference/BSD_metrics/metrics.py:51) count connected regions.
+ * scratch_dev: gcs_connected_scratch_bytes() bytes. out_dev may not alias labels_dev. */
+size_t gcs_connected_scratch_bytes(int B, int H, int W);
+int gcs_connected_regions(const int32_t *labels_dev, int B, int H, int W, void *scratch_dev,
+                          int32_t *out_dev, gcs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,9 @@ import numpy as np
 from scipy import ndimage as ndi
 
 
+_CROSS3 = ndi.generate_binary_structure(2, 1)
+
+
 # --------------------------------------------------------------------------- bank
 def bank(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0), bandwidth=1.0):
     """SPEC.md §2. Returns (tapq int64 [F,2,ks,ks], shift)."""
@@ -152,8 +155,26 @@ def segment_batch(imgs, mode="per_image", **kw):
     return lab.reshape(b, h, w).astype(np.int32)
 
 
+# -------------------------------------------------------------- connected regions
+def connected_regions(lab: np.ndarray) -> np.ndarray:
+    """SPEC.md §7: 4-connected components of equal labels, ids in raster order of first pixel."""
+    lab = np.asarray(lab)
+    comp = np.zeros(lab.shape, np.int64)
+    n = 0
+    for v in np.unique(lab):
+        c, m = ndi.label(lab == v, structure=_CROSS3)
+        comp[c > 0] = c[c > 0] + n
+        n += m
+    # renumber by first occurrence in raster order
+    flat = comp.ravel()
+    _, first = np.unique(flat, return_index=True)
+    order = np.argsort(first)                       # component ids (1-based, sorted) by first pixel
+    remap = np.empty(n + 1, np.int64)
+    remap[np.unique(flat)[order]] = np.arange(n)
+    return remap[flat].reshape(lab.shape).astype(np.int32)
+
+
 # ------------------------------------------------------------------------ scoring
-_CROSS3 = ndi.generate_binary_structure(2, 1)
 _SQ5 = np.ones((5, 5), bool)
 
 

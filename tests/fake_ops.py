@@ -74,5 +74,8 @@ class OracleOps:
         new = np.where(cnt > 0, (2 * s[:, :, :-1] + cnt) // np.maximum(2 * cnt, 1), c)
         cent.copy_(torch.from_numpy(new.astype(np.uint16).view(np.int16)))
 
+    def connected_regions(self, labels_i32, out):
+        out.copy_(torch.from_numpy(np.stack([so.connected_regions(l) for l in labels_i32.numpy()])))
+
     def labels_widen(self, labels, b, h, w, out):
         out.copy_(torch.from_numpy(labels["lab"].reshape(b, h, w).astype(np.int32)))

@@ -59,3 +59,11 @@ def test_synthetic_shards_tile_the_global_batch():
     full = synthetic_batch(5, 16, 24, seed=7)
     assert np.array_equal(np.concatenate([synthetic_shard(0, 2, 16, 24, seed=7), synthetic_shard(2, 3, 16, 24, seed=7)]), full)
     assert full.dtype == np.uint8 and len({im.tobytes() for im in full}) == 5
+
+
+def test_connectivity_option_relabels_connected_regions():
+    imgs = synthetic_batch(2, 24, 40, seed=9)
+    seg = Segmenter(ops=OracleOps(make_bank()), n_iter=3, connectivity=True)
+    out = seg.segment_device(torch.from_numpy(imgs)).numpy()
+    for b in range(2):
+        assert np.array_equal(out[b], so.connected_regions(so.segment(imgs[b], n_iter=3)))

@@ -104,3 +104,24 @@ def test_oracle_reproduces_committed_path_golden():
         lab, cent = co.kmeans(flat[None], 8, 10)
         assert np.array_equal(lab.reshape(h, w), g["labels_" + str(i)])
         assert np.array_equal(cent, g["centroids_" + str(i)])
+
+
+def test_connected_regions_hand_cases():
+    lab = np.array([[0, 0, 1, 1],
+                    [2, 0, 1, 0],
+                    [2, 2, 1, 0],
+                    [0, 2, 2, 0]])
+    #   components in raster order of first pixel: A={0,0,(1,1)}, B={1,1,1,1}, C={2,2,2,2,2}, D={(1,3),(2,3),(3,3)}, E={(3,0)}
+    want = np.array([[0, 0, 1, 1],
+                     [2, 0, 1, 3],
+                     [2, 2, 1, 3],
+                     [4, 2, 2, 3]])
+    assert np.array_equal(so.connected_regions(lab), want)
+    # diagonal neighbours are NOT connected (4-connectivity)
+    chk = np.indices((4, 4)).sum(axis=0) & 1
+    assert so.connected_regions(chk).max() == 15
+    # a constant map is one region; ids are dense
+    assert so.connected_regions(np.zeros((5, 7), int)).max() == 0
+    rng = np.random.default_rng(0)
+    r = so.connected_regions(rng.integers(0, 3, (20, 30)))
+    assert np.array_equal(np.unique(r), np.arange(r.max() + 1))
