@@ -41,6 +41,9 @@ static int hip_fail(hipError_t e, const char *what) {
 extern "C" int gcs_abi_version(void) { return GCS_ABI_VERSION; }
 extern "C" const char *gcs_last_error(void) { return g_err; }
 
+#ifndef GCS_KP_TP
+#define GCS_KP_TP 256
+#endif
 // ------------------------------------------------------------------------- geometry (host)
 static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 static inline int mtiles(int F) { return (F + 7) / 8; }
@@ -68,13 +71,13 @@ extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
 // workgroup's int32 accumulators must not overflow (<= 65536 pixels); upper bound: at least
 // 8 tiles per workgroup to amortise its prologue.
 #ifndef GCS_KP_SLOTS
-#define GCS_KP_SLOTS 768
+#define GCS_KP_SLOTS (768 * 256 / GCS_KP_TP)
 #endif
 extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t px = gcs_feature_plane_stride(H, W);
     const size_t need = (px + 65535) / 65536;
-    size_t most = px / 256 / 8;
+    size_t most = px / GCS_KP_TP / 8;
     if (most < 1) most = 1;
     size_t want = (GCS_KP_SLOTS + (size_t)B - 1) / (size_t)B;
     if (want > most) want = most;
@@ -133,11 +136,15 @@ extern "C" int gcs_bank_pack(const int16_t *tapq, int F, int ks, int8_t *packed,
     return GCS_OK;
 }
 
-// Feature slab addressing (tile-major): [B][tile][D][256 px] uint16, tile = flat pixel index
-// pp = y*pitch + x divided by 256. One k-means tile (all D planes of 256 pixels) is a single
-// contiguous D*512-byte run; 8-pixel (16-byte) groups never straddle a tile.
+// Feature slab addressing (tile-major): [B][tile][D][KP_TP px] uint16, tile = flat pixel index
+// pp = y*pitch + x divided by KP_TP (the k-means tile). One k-means tile (all D planes of KP_TP pixels)
+// is a single contiguous run; 8-pixel (16-byte) groups never straddle a tile.
+#ifndef GCS_KP_TP
+#define GCS_KP_TP 256
+#endif
+constexpr int KP_TP = GCS_KP_TP;          // pixels per k-means tile = threads per k-means workgroup (64 px per wave)
 __device__ __forceinline__ size_t slab_index(size_t image_tile0, int D, int d, int pp) {
-    return ((image_tile0 + (size_t)(pp >> 8)) * D + d) * 256 + (pp & 255);
+    return ((image_tile0 + (size_t)(pp / KP_TP)) * D + d) * KP_TP + (pp % KP_TP);
 }
 
 // ================================================================================ Gabor
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                         if (FULLF || f < F) {
                             // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
                             // signed MFMA digits for the k-means pass, which stages them untouched
-                            uint16_t *dst = feats + slab_index((size_t)b * (pstride >> 8), D, c * F + f, oy * pitch + ox);
+                            uint16_t *dst = feats + slab_index((size_t)b * (pstride / KP_TP), D, c * F + f, oy * pitch + ox);
                             *reinterpret_cast<uint4 *>(dst) =
                                 make_uint4(outp[mt][g][0] ^ 0x80808080u, outp[mt][g][1] ^ 0x80808080u,
                                            outp[mt][g][2] ^ 0x80808080u, outp[mt][g][3] ^ 0x80808080u);
@@ -415,7 +422,7 @@ __global__ void unpack_kernel(const uint16_t *__restrict__ feats, int H, int W, 
         const size_t pl = i / ((size_t)H * W);
         const int rem = (int)(i % ((size_t)H * W));
         const int D_ = (int)(planes_per_image);
-        out[i] = feats[slab_index((pl / D_) * (pstride >> 8), D_, (int)(pl % D_), (rem / W) * pitch + rem % W)] ^ 0x8080u;
+        out[i] = feats[slab_index((pl / D_) * (pstride / KP_TP), D_, (int)(pl % D_), (rem / W) * pitch + rem % W)] ^ 0x8080u;
     }
 }
 
@@ -438,7 +445,7 @@ __global__ void kmeans_init_kernel(const uint16_t *__restrict__ feats, int H, in
         const int j = i / D, d = i % D;
         const long p = ((2L * j + 1) * P) / (2L * k);
         const int y = (int)(p / W), x = (int)(p % W);
-        cent[((size_t)set * k + j) * D + d] = feats[slab_index((size_t)set * (pstride >> 8), D, d, y * pitch + x)] ^ 0x8080u;
+        cent[((size_t)set * k + j) * D + d] = feats[slab_index((size_t)set * (pstride / KP_TP), D, d, y * pitch + x)] ^ 0x8080u;
     }
 }
 
@@ -462,7 +469,7 @@ __global__ void features_gather_kernel(const uint16_t *__restrict__ feats, int p
         const int r = i / D, d = i % D;
         const int b = byx[3 * r], y = byx[3 * r + 1], x = byx[3 * r + 2];
         out[i] = b < 0 ? (uint16_t)0
-                       : (uint16_t)(feats[slab_index((size_t)b * (pstride >> 8), D, d, y * pitch + x)] ^ 0x8080u);
+                       : (uint16_t)(feats[slab_index((size_t)b * (pstride / KP_TP), D, d, y * pitch + x)] ^ 0x8080u);
     }
 }
 
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
 
     const int ppr = pitch >> 1; // pixel pairs per row
     const long npairs = (long)H * ppr;
-    const size_t tile0 = (size_t)b * (plane >> 8);          // slab holds x ^ 0x8080, tile-major
+    const size_t tile0 = (size_t)b * (plane / KP_TP);          // slab holds x ^ 0x8080, tile-major
     const int rep = tid & (R - 1);
 
     for (long q = (long)part * 256 + tid; q < npairs; q += (long)parts * 256) {
@@ -622,7 +629,6 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
-constexpr int KP_TP = 256;                // pixels per tile: 4 waves x 64
 constexpr int KP_ROWS = 80;               // plane rows held in LDS
 constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
 constexpr int KP_DSTEPS = KP_ROWS / 16;   // assign K-steps: 16 planes = 32 byte-features each
@@ -632,7 +638,7 @@ constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-
 #define GCS_KP_WAVES 3
 #endif
 template <int KT, int NST, bool EXACT>   // NST = staging chunks per thread >= ceil(D/8); EXACT: D == 8*NST
-__global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
+__global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
     int D, int K, int per_image, int parts, int x_first, int x_step, int row_lo, int row_hi,
     uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
@@ -651,7 +657,8 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
     //      key_j = base_j - 32 R0 - 8192 R1 - 2^21 R2 = 16 * score_j + j, so ONE 64-bit minimum yields the
     //      best score and the lowest index on ties. 16 lanes per cluster, folded with lane shuffles.
     {
-        const int j = tid >> 4, sub = tid & 15;
+      for (int j = tid >> 4; j < 16; j += KP_TP / 16) {
+        const int sub = tid & 15;
         long long nrm = 0, scl = 0, sch = 0;
         if (j < K)
             for (int d = sub; d < D; d += 16) {
@@ -671,6 +678,7 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
             const long long g = (128 * scl - q) + 256 * (128 * (sch + scl) - 2 * q) + 65536 * (128 * sch - q);
             s_const[j] = j < K ? 16 * (nrm - 2 * g) + j : (1LL << 62) + j;
         }
+      }
     }
     // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
     if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
@@ -713,15 +721,15 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
     //      load / write with exec masking and drain vmcnt(0) before each write. Chunk rows beyond the
     //      last plane (D not a multiple of 8, or a coarser NST bucket) are clamped to plane D-1: they
     //      re-read and re-write row D-1 with its own data.
-    const int sd0 = tid >> 5, spo = 8 * (tid & 31);
+    const int sd0 = tid / (KP_TP / 8), spo = 8 * (tid % (KP_TP / 8));
     v4i st[NST];
     int srow[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) srow[i] = EXACT ? sd0 + 8 * i : min(sd0 + 8 * i, D - 1);
     auto stage_load = [&](int tile) {
-        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * D * KP_TP) + (tid & 31);
+        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * D * KP_TP) + (tid % (KP_TP / 8));
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = src[srow[i] * 32];
+        for (int i = 0; i < NST; ++i) st[i] = src[srow[i] * (KP_TP / 8)];
     };
     auto stage_write = [&]() {
         unsigned char *dst = &s_tile[spo * 2];
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
 
     // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row
     int *red = reinterpret_cast<int *>(s_tile);               // [16][160]
-    for (int i = tid; i < 16 * KP_NT * 16; i += 256) red[i] = 0;
+    for (int i = tid; i < 16 * KP_NT * 16; i += KP_TP) red[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < KP_NT; ++nt)
@@ -869,7 +877,7 @@ __global__ __launch_bounds__(256, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) 
     __syncthreads();
     const int D1 = D + 1;
     uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
-    for (int i = tid; i < K * D1; i += 256) {
+    for (int i = tid; i < K * D1; i += KP_TP) {
         const int j = i / D1, e = i % D1;
         const long long nj = -(long long)red[j * (KP_NT * 16) + cnt_bp] / 128;
         long long out = nj;
@@ -934,7 +942,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     else                                                                                                      \
         GCS_KP_LAUNCH2(KT_, NST_, false)
 #define GCS_KP_LAUNCH2(KT_, NST_, EX_)                                                                        \
-    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_>), dim3(parts, B), dim3(256), 0, stream, feats, cent, H, \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_>), dim3(parts, B), dim3(KP_TP), 0, stream, feats, cent, H, \
                        W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, KP_TP % pitch,                         \
                        (int)(((long long)parts * KP_TP) % pitch), row_lo, row_hi, labels, partials)
         const int nst = (D + 7) / 8;
