@@ -76,21 +76,21 @@ class TimedOps:
     def __getattr__(self, name):
         return getattr(self._ops, name)
 
-    def _timed(self, key, fn, *a):
+    def _timed(self, key, fn, *a, **kw):
         if not self.enabled:
-            return fn(*a)
+            return fn(*a, **kw)
         s = self._torch.cuda.Event(enable_timing=True)
         e = self._torch.cuda.Event(enable_timing=True)
         s.record()
-        fn(*a)
+        fn(*a, **kw)
         e.record()
         self.events[key].append((s, e))
 
-    def gabor_features(self, *a):
-        return self._timed("gabor", self._ops.gabor_features, *a)
+    def gabor_features(self, *a, **kw):
+        return self._timed("gabor", self._ops.gabor_features, *a, **kw)
 
-    def assign_accumulate(self, *a):
-        return self._timed("assign", self._ops.assign_accumulate, *a)
+    def assign_accumulate(self, *a, **kw):
+        return self._timed("assign", self._ops.assign_accumulate, *a, **kw)
 
     def mean_ms(self, key):
         ev = self.events[key]

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -35,7 +35,7 @@ SIGNATURES = {
     "gcs_features_unpack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_features_gather": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_kmeans_reduce": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_finalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gcs_labels_widen": (_i, [_vp, _i, _i, _i, _vp, _vp]),

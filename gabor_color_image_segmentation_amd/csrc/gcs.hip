@@ -640,7 +640,7 @@ constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-
 template <int KT, int NST, bool EXACT>   // NST = staging chunks per thread >= ceil(D/8); EXACT: D == 8*NST
 __global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
-    int D, int K, int per_image, int parts, int x_first, int x_step, int row_lo, int row_hi,
+    int D, int K, int per_image, int parts, int reverse, int row_lo, int row_hi,
     uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
@@ -742,17 +742,20 @@ __global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)
     const unsigned eqr = (unsigned)un * 0x01010101u;
     const int cnt_bp = 2 * D;
 
-    // x coordinate of the tile's first pixel, advanced without divisions (x_step = (parts*256) % pitch)
-    int x0 = (int)(((long long)part * x_first) % pitch);   // x_first = 256 % pitch; once per workgroup
-
-    int tile = part;
-    if (tile < ntiles) stage_load(tile);
-    for (; tile < ntiles; tile += parts) {
+    // Sweep order: workgroup `part` takes logical tiles part, part+parts, ...; on odd passes the physical
+    // order is reversed (boustrophedon), so a pass starts on the tiles the previous pass read last, i.e. on
+    // what is still in the 256 MiB Infinity Cache.
+    auto phys = [&](int lt) { return reverse ? ntiles - 1 - lt : lt; };
+    int ltile = part;
+    if (ltile < ntiles) stage_load(phys(ltile));
+    for (; ltile < ntiles; ltile += parts) {
+        const int tile = phys(ltile);
         stage_write();
         __syncthreads();
-        if (tile + parts < ntiles) stage_load(tile + parts);   // in flight during the MFMAs
+        if (ltile + parts < ntiles) stage_load(phys(ltile + parts));   // in flight during the MFMAs
 
         const int pp0 = tile * KP_TP;
+        const int x0 = pp0 % pitch;               // column of the tile's first pixel (one modulo per tile)
         // -------- assign: two 32-pixel sub-tiles per wave
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -838,8 +841,6 @@ __global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)
                 labels[(size_t)b * pstride + pp] = (uint8_t)bj;
             }
         }
-        x0 += x_step;
-        if (x0 >= pitch) x0 -= pitch;
         // -------- update: one-hot MFMA over this wave's 64 pixels
         {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
@@ -919,8 +920,8 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, int
 }
 
 extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
-                                            int D, int k, int n_sets, int row_lo, int row_hi, uint8_t *labels,
-                                            uint64_t *partials, gcs_stream_t stream) {
+                                            int D, int k, int n_sets, int row_lo, int row_hi, int reverse,
+                                            uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
     if (!feats || !cent || !labels || !partials)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer");
     if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
@@ -935,7 +936,6 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
         const int pitch = (int)gcs_feature_pitch(W);
         if ((long long)H * pitch > 0x7fffffffLL / 2) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large");
         const int pstride = (int)gcs_feature_plane_stride(H, W);
-        // NOTE: the kernel derives each workgroup's first x from part; x_first is per-part below
 #define GCS_KP_LAUNCH(KT_, NST_)                                                                              \
     if (D == 8 * NST_)                                                                                        \
         GCS_KP_LAUNCH2(KT_, NST_, true);                                                                      \
@@ -943,8 +943,8 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
         GCS_KP_LAUNCH2(KT_, NST_, false)
 #define GCS_KP_LAUNCH2(KT_, NST_, EX_)                                                                        \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_>), dim3(parts, B), dim3(KP_TP), 0, stream, feats, cent, H, \
-                       W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, KP_TP % pitch,                         \
-                       (int)(((long long)parts * KP_TP) % pitch), row_lo, row_hi, labels, partials)
+                       W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, reverse ? 1 : 0, row_lo, row_hi,      \
+                       labels, partials)
         const int nst = (D + 7) / 8;
         if (k <= 8) {
             if (nst <= 3) { GCS_KP_LAUNCH(1, 3); }

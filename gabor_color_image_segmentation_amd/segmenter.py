@@ -13,12 +13,15 @@ PyTorch is plumbing only: device memory, the current HIP stream and torch.distri
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
 from . import _lib
 from .bank import GaborBank, make_bank
 
+# Measurement switch: GCS_NO_REVERSE=1 sweeps every Lloyd pass in the same direction (results identical).
+_NO_REVERSE = bool(os.environ.get("GCS_NO_REVERSE"))
 _SLAB_BUDGET = 16 << 30    # feature-slab bytes per group; measured: one big launch beats cache-sized groups
 
 
@@ -87,11 +90,12 @@ class HipOps:
         _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
                                             cent.data_ptr(), self._stream()), "gcs_kmeans_init")
 
-    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None):
+    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None, reverse=False):
         lo, hi = rows if rows is not None else (0, h)
         _lib.check(self.lib.gcs_kmeans_assign_accumulate(
             feats.data_ptr(), cent.data_ptr(), b, h, w, self.bank.n_features, k, n_sets, lo, hi,
-            labels.data_ptr(), partials.data_ptr(), self._stream()), "gcs_kmeans_assign_accumulate")
+            1 if reverse else 0, labels.data_ptr(), partials.data_ptr(), self._stream()),
+            "gcs_kmeans_assign_accumulate")
 
     def features_gather(self, feats, b, h, w, byx):
         """byx: (n,3) int32 device tensor of (image, row, col); image < 0 -> zero row. -> (n,D) int16."""
@@ -167,7 +171,8 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
                         src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
                         group=dist_group)
     for t in range(n_iter):
-        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows)
+        # alternate the sweep direction: a pass starts where the previous one ended (Infinity Cache reuse)
+        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows, reverse=bool(t & 1) and not _NO_REVERSE)
         if t < n_iter - 1:
             ops.reduce(partials, b, h, w, k, n_sets, sums)
             if dist is not None:

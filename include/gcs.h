@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 7
+#define GCS_ABI_VERSION 8
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -91,11 +91,14 @@ int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int D, i
 
 /* SPEC.md §4 assign + per-workgroup partial sums (one streaming pass over the slab).
  * Only rows [row_lo, row_hi) of each image vote in the sums (whole image: 0, H); halo rows of
- * a row-sharded image are labelled but do not vote. labels_dev: label slab; partials_dev:
+ * a row-sharded image are labelled but do not vote. `reverse` != 0 sweeps the slab back to front:
+ * alternate it from pass to pass so that each pass starts on what the previous one left in the
+ * Infinity Cache (results do not depend on it). labels_dev: label slab; partials_dev:
  * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). */
 int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
                                  int H, int W, int D, int k, int n_sets, int row_lo, int row_hi,
-                                 uint8_t *labels_dev, uint64_t *partials_dev, gcs_stream_t stream);
+                                 int reverse, uint8_t *labels_dev, uint64_t *partials_dev,
+                                 gcs_stream_t stream);
 
 /* partials -> sums_dev int64 [n_sets][k][D+1] ([..][D] = count). Deterministic slab
  * reduction (no float, no atomics). In global mode the caller all-reduces sums_dev across

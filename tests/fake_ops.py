@@ -47,7 +47,7 @@ class OracleOps:
                 out[i] = feats["x"][bi][y * w + x]
         return torch.from_numpy(out.view(np.int16))
 
-    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None):
+    def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None, reverse=False):
         c = cent.numpy().view(np.uint16).astype(np.int64)
         lo, hi = rows if rows is not None else (0, h)
         vote = np.zeros((h, w), bool)
