@@ -26,6 +26,31 @@ def test_bank_matches_oracle_and_golden():
     assert np.array_equal(g["tapq"], b.tapq) and int(g["shift"]) == b.shift
 
 
+@pytest.mark.parametrize("name,ns,no", [("b4x6", 4, 6), ("b8x8", 8, 8)])
+def test_float_taps_are_the_scikit_image_gabor_kernel(name, ns, no):
+    """SPEC.md §2 pinned to a published definition: skimage.filters.gabor_kernel(frequency, theta,
+    bandwidth) (fixture from tests/golden/make_bank_golden.py). Same envelope, bandwidth -> sigma rule,
+    rotation convention and phase; only the gain differs (unit DC gain on the truncated 15x15 frame
+    instead of skimage's 1/(2 pi sigma^2)), and both oracle and product share it."""
+    import math
+    z = np.load(os.path.join(GOLD, "bank_skimage.npz"))
+    ref = z[name][:, 8:23, 8:23]                                   # central 15x15 of the 31x31 frame
+    taps = gabor_taps(n_scales=ns, n_orient=no)
+    kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * 3.0
+    dy, dx = np.mgrid[-7:8, -7:8]
+    for f in range(ns * no):
+        sigma = kappa / (0.4 / math.sqrt(2.0) ** (f // no))
+        gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
+        mine = (taps[f, 0] + 1j * taps[f, 1]) * gain
+        support = np.abs(ref[f]) > 0                               # skimage truncates at 3 sigma
+        assert support.sum() >= 49
+        assert np.abs(mine - ref[f])[support].max() < 1e-15
+        # the quantised bank the kernels run is that kernel to within half an LSB
+        b = make_bank(n_scales=ns, n_orient=no)
+        q = (b.tapq[f, 0] + 1j * b.tapq[f, 1]) * gain / 2.0 ** b.exponent
+        assert np.abs(q - ref[f])[support].max() <= 0.7072 * gain / 2.0 ** b.exponent
+
+
 def test_symmetry_and_zero_dc_of_imaginary_part():
     b = make_bank()
     re, im = b.tapq[:, 0].astype(np.int64), b.tapq[:, 1].astype(np.int64)
