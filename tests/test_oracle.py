@@ -125,3 +125,21 @@ def test_connected_regions_hand_cases():
     rng = np.random.default_rng(0)
     r = so.connected_regions(rng.integers(0, 3, (20, 30)))
     assert np.array_equal(np.unique(r), np.arange(r.max() + 1))
+
+
+def test_integer_kmeans_tracks_scikit_learn_lloyd():
+    """The integer Lloyd schedule of SPEC.md §4 against a published implementation: scikit-learn's
+    float64 Lloyd (same init pixels, max_iter = n_iter - 1 so that its final labels are also
+    assign(c^{n_iter-1})). Integer centroid rounding moves centroids by < 2 Q7 units (1/64 grey
+    level) and flips only boundary pixels."""
+    KMeans = pytest.importorskip("sklearn.cluster").KMeans
+    inp = np.load(os.path.join(GOLD, "bsd_inputs.npz"))
+    g = np.load(os.path.join(GOLD, "path_golden.npz"))
+    i = str(inp["ids"][0])
+    tapq, shift = so.bank()
+    x = so.gabor_features(inp["img_" + i], tapq, shift).reshape(72, -1).T.astype(np.float64)
+    km = KMeans(n_clusters=8, init=so.kmeans_init(x, 8).astype(np.float64), n_init=1, max_iter=9,
+                tol=0.0, algorithm="lloyd").fit(x)
+    assert km.n_iter_ == 9
+    assert (km.labels_ == g["labels_" + i].ravel()).mean() > 0.995
+    assert np.abs(km.cluster_centers_ - g["centroids_" + i]).max() < 4.0
