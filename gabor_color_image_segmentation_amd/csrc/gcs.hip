@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// One Lloyd pass on the matrix cores (D <= 79). Per 256-pixel tile, staged ONCE in LDS as
+// One Lloyd pass on the matrix cores (D <= 207: 80-row LDS tile for D <= 79, 208-row tile above).
+// Per 256-pixel tile, staged ONCE in LDS as
 // u16 planes (each byte offset by -128 so it is a signed MFMA digit):
 //   assign:  scores[(j,pat)][px] = A_pat[(j,pat)][k] * X[k][px] on v_mfma_i32_32x32x32_i8, k =
 //            (plane, byte). Patterns per cluster j: LL = cl*xl, M = ch*xl + cl*xh, HH = ch*xh, so
@@ -629,19 +630,23 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
-constexpr int KP_ROWS = 80;               // plane rows held in LDS
 constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
-constexpr int KP_DSTEPS = KP_ROWS / 16;   // assign K-steps: 16 planes = 32 byte-features each
-constexpr int KP_NT = KP_ROWS / 8;        // update N-tiles: 8 planes = 16 byte-planes each
+constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 42 KB LDS, 3 workgroups / CU
+constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 110 KB LDS, 1 workgroup / CU
 
 #ifndef GCS_KP_WAVES
 #define GCS_KP_WAVES 3
 #endif
-template <int KT, int NST, bool EXACT>   // NST = staging chunks per thread >= ceil(D/8); EXACT: D == 8*NST
-__global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES : 2)) void kmeans_pass_mfma_kernel(
+// DSTEPS = assign K-steps (16 planes = 32 byte-features each); LDS holds ROWS = 16*DSTEPS plane rows (>= D + 1:
+// the spare row D is the count row); the update has NT = 2*DSTEPS N-tiles (8 planes = 16 byte-planes each).
+// NST = staging chunks per thread >= ceil(D/8); EXACT: D == 8*NST.
+template <int KT, int NST, bool EXACT, int DSTEPS>
+__global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (NST <= 6 || (EXACT && NST <= 9)) ? GCS_KP_WAVES
+                                     : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const uint16_t *__restrict__ feats, const uint16_t *__restrict__ cent, int H, int W, int pitch, int pstride,
     int D, int K, int per_image, int parts, int reverse, int row_lo, int row_hi,
     uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
@@ -777,31 +782,21 @@ __global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)
                 const unsigned addr = (unsigned)(size_t)&s_tile[(8 * h + (i16 >> 2)) * KP_PITCH +
                                                                 (wave * 64 + sub * 32 + 16 * pxblk + 4 * (i16 & 3)) * 2];
                 typedef int v2i __attribute__((ext_vector_type(2)));
-                v2i f0a, f0b, f1a, f1b, f2a, f2b, f3a, f3b, f4a, f4b;
-                static_assert(KP_DSTEPS == 5, "five K-steps are read in one asm statement");
-                asm volatile(
-                    "ds_read_b64_tr_b16 %0, %10 offset:%c11\n\t"
-                    "ds_read_b64_tr_b16 %1, %10 offset:%c12\n\t"
-                    "ds_read_b64_tr_b16 %2, %10 offset:%c13\n\t"
-                    "ds_read_b64_tr_b16 %3, %10 offset:%c14\n\t"
-                    "ds_read_b64_tr_b16 %4, %10 offset:%c15\n\t"
-                    "ds_read_b64_tr_b16 %5, %10 offset:%c16\n\t"
-                    "ds_read_b64_tr_b16 %6, %10 offset:%c17\n\t"
-                    "ds_read_b64_tr_b16 %7, %10 offset:%c18\n\t"
-                    "ds_read_b64_tr_b16 %8, %10 offset:%c19\n\t"
-                    "ds_read_b64_tr_b16 %9, %10 offset:%c20\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(f0a), "=&v"(f0b), "=&v"(f1a), "=&v"(f1b), "=&v"(f2a), "=&v"(f2b), "=&v"(f3a), "=&v"(f3b),
-                      "=&v"(f4a), "=&v"(f4b)
-                    : "v"(addr), "i"(0 * KP_PITCH), "i"(4 * KP_PITCH), "i"(16 * KP_PITCH), "i"(20 * KP_PITCH),
-                      "i"(32 * KP_PITCH), "i"(36 * KP_PITCH), "i"(48 * KP_PITCH), "i"(52 * KP_PITCH),
-                      "i"(64 * KP_PITCH), "i"(68 * KP_PITCH)
-                    : "memory");
-                bfr[0] = v4i{f0a[0], f0a[1], f0b[0], f0b[1]};
-                bfr[1] = v4i{f1a[0], f1a[1], f1b[0], f1b[1]};
-                bfr[2] = v4i{f2a[0], f2a[1], f2b[0], f2b[1]};
-                bfr[3] = v4i{f3a[0], f3a[1], f3b[0], f3b[1]};
-                bfr[4] = v4i{f4a[0], f4a[1], f4b[0], f4b[1]};
+                v2i fa[KP_DSTEPS], fb[KP_DSTEPS];
+#pragma unroll
+                for (int kk = 0; kk < KP_DSTEPS; ++kk)       // the DS offset field holds 16 bits: K-step base in the VGPR
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+                                 "ds_read_b64_tr_b16 %1, %2 offset:%c3"
+                                 : "=&v"(fa[kk]), "=&v"(fb[kk])
+                                 : "v"(addr + kk * 16 * KP_PITCH), "i"(4 * KP_PITCH)
+                                 : "memory");
+                // hipcc does not count asm loads: one explicit wait, then tie every destination register to it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int kk = 0; kk < KP_DSTEPS; ++kk) {
+                    asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
+                    bfr[kk] = v4i{fa[kk][0], fa[kk][1], fb[kk][0], fb[kk][1]};
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < KP_DSTEPS; ++kk)
@@ -868,7 +863,7 @@ __global__ __launch_bounds__(KP_TP, (KT == 1 && (NST <= 6 || (EXACT && NST <= 9)
     }
 
     // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row
-    int *red = reinterpret_cast<int *>(s_tile);               // [16][160]
+    int *red = reinterpret_cast<int *>(s_tile);               // [16][16 * KP_NT]
     for (int i = tid; i < 16 * KP_NT * 16; i += KP_TP) red[i] = 0;
     __syncthreads();
 #pragma unroll
@@ -931,29 +926,39 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     if (k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
     if (n_sets != 1 && n_sets != B)
         return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
-    if (D < KP_ROWS) { // matrix-core pass (the product path for every BASELINE bank with F <= 26)
+    if (D < 16 * KP_DSTEPS_WIDE) { // matrix-core pass (every BASELINE bank: 4x6 -> D = 72, 8x8 -> D = 192)
         const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
         const int pitch = (int)gcs_feature_pitch(W);
         if ((long long)H * pitch > 0x7fffffffLL / 2) return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large");
         const int pstride = (int)gcs_feature_plane_stride(H, W);
-#define GCS_KP_LAUNCH(KT_, NST_)                                                                              \
+#define GCS_KP_LAUNCH(KT_, NST_, DS_)                                                                         \
     if (D == 8 * NST_)                                                                                        \
-        GCS_KP_LAUNCH2(KT_, NST_, true);                                                                      \
+        GCS_KP_LAUNCH2(KT_, NST_, true, DS_);                                                                 \
     else                                                                                                      \
-        GCS_KP_LAUNCH2(KT_, NST_, false)
-#define GCS_KP_LAUNCH2(KT_, NST_, EX_)                                                                        \
-    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_>), dim3(parts, B), dim3(KP_TP), 0, stream, feats, cent, H, \
-                       W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, reverse ? 1 : 0, row_lo, row_hi,      \
+        GCS_KP_LAUNCH2(KT_, NST_, false, DS_)
+#define GCS_KP_LAUNCH2(KT_, NST_, EX_, DS_)                                                                   \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, EX_, DS_>), dim3(parts, B), dim3(KP_TP), 0, stream, feats, cent, \
+                       H, W, pitch, pstride, D, k, n_sets == B ? 1 : 0, parts, reverse ? 1 : 0, row_lo, row_hi,  \
                        labels, partials)
         const int nst = (D + 7) / 8;
-        if (k <= 8) {
-            if (nst <= 3) { GCS_KP_LAUNCH(1, 3); }
-            else if (nst <= 6) { GCS_KP_LAUNCH(1, 6); }
-            else if (nst <= 9) { GCS_KP_LAUNCH(1, 9); }
-            else { GCS_KP_LAUNCH(1, 10); }
+        if (D < 16 * KP_DSTEPS_NARROW) {
+            if (k <= 8) {
+                if (nst <= 3) { GCS_KP_LAUNCH(1, 3, KP_DSTEPS_NARROW); }
+                else if (nst <= 6) { GCS_KP_LAUNCH(1, 6, KP_DSTEPS_NARROW); }
+                else if (nst <= 9) { GCS_KP_LAUNCH(1, 9, KP_DSTEPS_NARROW); }
+                else { GCS_KP_LAUNCH(1, 10, KP_DSTEPS_NARROW); }
+            } else {
+                if (nst <= 9) { GCS_KP_LAUNCH(2, 9, KP_DSTEPS_NARROW); }
+                else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
+            }
+        } else if (k <= 8) {
+            if (nst <= 16) { GCS_KP_LAUNCH(1, 16, KP_DSTEPS_WIDE); }
+            else if (nst <= 24) { GCS_KP_LAUNCH(1, 24, KP_DSTEPS_WIDE); }
+            else { GCS_KP_LAUNCH(1, 26, KP_DSTEPS_WIDE); }
         } else {
-            if (nst <= 9) { GCS_KP_LAUNCH(2, 9); }
-            else { GCS_KP_LAUNCH(2, 10); }
+            if (nst <= 16) { GCS_KP_LAUNCH(2, 16, KP_DSTEPS_WIDE); }
+            else if (nst <= 24) { GCS_KP_LAUNCH(2, 24, KP_DSTEPS_WIDE); }
+            else { GCS_KP_LAUNCH(2, 26, KP_DSTEPS_WIDE); }
         }
 #undef GCS_KP_LAUNCH
 #undef GCS_KP_LAUNCH2

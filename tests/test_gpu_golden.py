@@ -92,15 +92,15 @@ def test_k16_two_mfma_tiles_and_portrait(built):
 
 
 def test_wide_feature_vectors_use_the_generic_pass(built):
-    """D = 81 >= 80 planes: the non-MFMA k-means pass; still bit-exact."""
+    """D = 210 >= 208 planes: the non-MFMA k-means pass; still bit-exact."""
     from gabor_color_image_segmentation_amd import Segmenter
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     imgs = synthetic_batch(2, 40, 56, seed=6)
-    s = Segmenter(n_scales=3, n_orient=9, k=4, n_iter=3)
-    assert s.bank.n_features == 81
+    s = Segmenter(n_scales=7, n_orient=10, k=4, n_iter=3)
+    assert s.bank.n_features == 210
     got = s.segment_batch(imgs)
     for b in range(2):
-        assert np.array_equal(got[b], so.segment(imgs[b], n_scales=3, n_orient=9, k=4, n_iter=3))
+        assert np.array_equal(got[b], so.segment(imgs[b], n_scales=7, n_orient=10, k=4, n_iter=3))
 
 
 def test_sixty_four_filter_bank_features(built):
@@ -143,7 +143,7 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_oracle(built):
 
 
 def test_sixty_four_filter_bank_full_segment(built):
-    """BASELINE config 4 end to end (D = 192: four Gabor launches, generic k-means pass)."""
+    """BASELINE config 4 end to end (D = 192: four Gabor launches, wide MFMA k-means pass)."""
     from gabor_color_image_segmentation_amd import Segmenter
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     imgs = synthetic_batch(2, 40, 64, seed=23)

@@ -89,9 +89,12 @@ def test_global_codebook_bit_exact(torch_cuda):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("ns,no,ks,k", [(1, 1, 15, 3), (1, 4, 9, 5), (2, 5, 11, 8), (3, 8, 15, 16), (2, 13, 7, 4)])
+@pytest.mark.parametrize("ns,no,ks,k", [(1, 1, 15, 3), (1, 4, 9, 5), (2, 5, 11, 8), (3, 8, 15, 16), (2, 13, 7, 4),
+                                        (3, 9, 15, 4), (1, 43, 11, 5), (8, 8, 15, 8), (8, 8, 15, 13), (3, 23, 9, 16),
+                                        (3, 23, 9, 7)])
 def test_segment_small_and_ragged_feature_counts(torch_cuda, ns, no, ks, k):
-    """D = 3, 12, 30, 72, 78: every staging-chunk bucket of the MFMA k-means pass, D not a multiple of 8."""
+    """D = 3, 12, 30, 72, 78: every staging-chunk bucket of the narrow MFMA k-means pass, D not a multiple of 8;
+    D = 81, 129, 192, 207: every bucket of the wide (208-row) pass, k <= 8 and k > 8."""
     from gabor_color_image_segmentation_amd import Segmenter
     imgs = _synth(2, 40, 72, seed=31)
     seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=4)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time the stages of the path for any bank: tools/stage_time.py [B] [n_scales] [n_orient] [k] [mode].
+
+Prints the Gabor stage, one Lloyd pass and the whole segment_device step (n_iter = 10) on B synthetic
+321x481 images, with the algorithmic GB/s of the pass ((2D+1) B/px) and the int8 TOP/s of the bank.
+BASELINE config 4 (8x8 bank, D = 192): tools/stage_time.py 64 8 8."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gabor_color_image_segmentation_amd import Segmenter
+from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+a = sys.argv[1:]
+B = int(a[0]) if len(a) > 0 else 64
+ns = int(a[1]) if len(a) > 1 else 4
+no = int(a[2]) if len(a) > 2 else 6
+k = int(a[3]) if len(a) > 3 else 8
+mode = a[4] if len(a) > 4 else "global"
+H, W = 321, 481
+imgs = torch.from_numpy(synthetic_shard(0, B, H, W)).cuda()
+seg = Segmenter(n_scales=ns, n_orient=no, k=k)
+D = seg.bank.n_features
+ws = seg._workspace(B, H, W, mode)
+n_sets = B if mode == "per_image" else 1
+
+
+def timed(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for s, e in ev:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    return sorted(s.elapsed_time(e) for s, e in ev)[n // 2]
+
+
+tg = timed(lambda: seg.ops.gabor_features(imgs, ws["feats"]))
+seg.ops.kmeans_init(ws["feats"], B, H, W, k, n_sets, ws["cent"])
+tp = timed(lambda: seg.ops.assign_accumulate(ws["feats"], ws["cent"], B, H, W, k, n_sets, ws["labels"], ws["partials"]))
+ts = timed(lambda: seg.segment_device(imgs, mode=mode), n=5, warm=1)
+px = B * H * W
+print(f"B={B} bank {ns}x{no} D={D} k={k} {mode}: gabor {tg:.3f} ms ({2*225*4*seg.bank.n_filters*3*px/tg/1e9:.0f} TOP/s, "
+      f"{(3+2*D)*px/tg/1e6:.0f} GB/s) | pass {tp:.3f} ms ({(2*D+1)*px/tp/1e6:.0f} GB/s alg) | "
+      f"step {ts:.2f} ms = {px/ts/1e3:.0f} Mpix/s")
