@@ -978,41 +978,78 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 
 // sums[set][e] = sum over the partial rows of the images in this set. Integer sums: any
 // order gives the same bits. Block = 16 elements x 16 row slices, folded through LDS.
+// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in
+// between): every thread also sums the count column of its element's cluster (L2 hits), so no second
+// kernel and no cross-block dependency is needed.
+template <bool FIN>
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
-                                                            int rows_per_set, int row_len,
-                                                            long long *__restrict__ sums) {
+                                                            int rows_per_set, int row_len, int D1,
+                                                            long long *__restrict__ sums,
+                                                            uint16_t *__restrict__ cent) {
     __shared__ uint64_t s_part[16][17];
+    __shared__ uint64_t s_cnt[16][17];
     const int set = blockIdx.y;
     const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
-    uint64_t s = 0;
+    uint64_t s = 0, c = 0;
     if (e < row_len) {
         const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
+        const int to_cnt = (e / D1) * D1 + (D1 - 1) - e;      // offset of this cluster's count column
 #pragma unroll 4
-        for (int r = slice; r < rows_per_set; r += 16) s += p[(size_t)r * row_len];
+        for (int r = slice; r < rows_per_set; r += 16) {
+            s += p[(size_t)r * row_len];
+            if (FIN) c += p[(size_t)r * row_len + to_cnt];
+        }
     }
     s_part[slice][el] = s;
+    if (FIN) s_cnt[slice][el] = c;
     __syncthreads();
     if (slice == 0 && e < row_len) {
-        uint64_t t = 0;
+        uint64_t t = 0, n = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += s_part[i][el];
-        sums[(size_t)set * row_len + e] = (long long)t;
+        for (int i = 0; i < 16; ++i) {
+            t += s_part[i][el];
+            if (FIN) n += s_cnt[i][el];
+        }
+        if (sums) sums[(size_t)set * row_len + e] = (long long)t;
+        if (FIN) {
+            const int j = e / D1, d = e - j * D1, D = D1 - 1;
+            if (d < D && n > 0)
+                cent[((size_t)set * (row_len / D1) + j) * D + d] = (uint16_t)((2 * t + n) / (2 * n));
+        }
     }
+}
+
+static int reduce_args_ok(const void *partials, int B, int H, int W, int D, int k, int n_sets, const char *who) {
+    if (!partials) return fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX) return fail(GCS_EINVAL, who);
+    if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_reduce: n_sets must be 1 or B");
+    return GCS_OK;
 }
 
 extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
                                  int64_t *sums, gcs_stream_t stream) {
-    if (!partials || !sums) return fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
-    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX)
-        return fail(GCS_EINVAL, "gcs_kmeans_reduce: bad shape");
-    if (n_sets != 1 && n_sets != B) return fail(GCS_EINVAL, "gcs_kmeans_reduce: n_sets must be 1 or B");
+    if (!sums) return fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
+    if (int rc = reduce_args_ok(partials, B, H, W, D, k, n_sets, "gcs_kmeans_reduce: bad shape")) return rc;
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
-                       rows_per_set, row_len, reinterpret_cast<long long *>(sums));
+    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
+                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
+    return GCS_OK;
+}
+
+extern "C" int gcs_kmeans_reduce_finalize(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
+                                          int64_t *sums, uint16_t *cent, gcs_stream_t stream) {
+    if (!cent) return fail(GCS_EINVAL, "gcs_kmeans_reduce_finalize: NULL pointer");
+    if (int rc = reduce_args_ok(partials, B, H, W, D, k, n_sets, "gcs_kmeans_reduce_finalize: bad shape")) return rc;
+    const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
+    const int row_len = k * (D + 1);
+    const int rows_per_set = n_sets == B ? parts : B * parts;
+    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
+                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_reduce_finalize");
     return GCS_OK;
 }
 
@@ -1037,19 +1074,31 @@ extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D
     return GCS_OK;
 }
 
-__global__ void widen_kernel(const uint8_t *__restrict__ labels, int H, int W, int pitch, size_t pstride, size_t n,
-                             int32_t *__restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t by = i / W; // b*H + y
-        out[i] = labels[(by / H) * pstride + (by % H) * pitch + i % W];
+// One block row per image row; a thread widens 4 labels (one aligned dword of the slab: pitch % 8 == 0).
+__global__ __launch_bounds__(256) void widen_kernel_rows(const uint8_t *__restrict__ labels, int H, int W, int pitch,
+                                                         size_t pstride, int row0, int32_t *__restrict__ out) {
+    const int by = row0 + blockIdx.y;                // b*H + y
+    const int b = by / H, y = by - b * H;
+    const unsigned *src = reinterpret_cast<const unsigned *>(labels + (size_t)b * pstride + (size_t)y * pitch);
+    int32_t *dst = out + (size_t)by * W;
+    for (int x4 = blockIdx.x * blockDim.x + threadIdx.x; 4 * x4 < W; x4 += gridDim.x * blockDim.x) {
+        const unsigned v = src[x4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * x4 + e < W) dst[4 * x4 + e] = (int32_t)((v >> (8 * e)) & 255u);
     }
 }
 
 extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream) {
     if (!labels || !out) return fail(GCS_EINVAL, "gcs_labels_widen: NULL pointer");
-    if (B <= 0 || H <= 0 || W <= 0) return fail(GCS_EINVAL, "gcs_labels_widen: bad shape");
-    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, stream, labels, H, W, (int)gcs_feature_pitch(W),
-                       gcs_feature_plane_stride(H, W), (size_t)B * H * W, out);
+    if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H > 0x7fffffffLL)
+        return fail(GCS_EINVAL, "gcs_labels_widen: bad shape");
+    const int rows = B * H;                          // grid.y is limited to 65535: fold the rest into z-less chunks
+    for (int r0 = 0; r0 < rows; r0 += 65535) {
+        const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(widen_kernel_rows, dim3((W / 4 + 255) / 256 > 0 ? (W / 4 + 255) / 256 : 1, nr), dim3(256), 0,
+                           stream, labels, H, W, (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), r0, out);
+    }
     GCS_CHECK_LAUNCH("gcs_labels_widen");
     return GCS_OK;
 }

@@ -114,6 +114,12 @@ class HipOps:
         _lib.check(self.lib.gcs_kmeans_finalize(sums.data_ptr(), n_sets, k, self.bank.n_features,
                                                 cent.data_ptr(), self._stream()), "gcs_kmeans_finalize")
 
+    def reduce_finalize(self, partials, b, h, w, k, n_sets, sums, cent):
+        """Single-rank update in one launch (reduce + finalize; no collective in between)."""
+        _lib.check(self.lib.gcs_kmeans_reduce_finalize(partials.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
+                                                       sums.data_ptr(), cent.data_ptr(), self._stream()),
+                   "gcs_kmeans_reduce_finalize")
+
     def connected_regions(self, labels_i32, out):
         """SPEC.md §7 on an int32 (B,H,W) device tensor."""
         b, h, w = labels_i32.shape
@@ -174,10 +180,12 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
         # alternate the sweep direction: a pass starts where the previous one ended (Infinity Cache reuse)
         ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows, reverse=bool(t & 1) and not _NO_REVERSE)
         if t < n_iter - 1:
-            ops.reduce(partials, b, h, w, k, n_sets, sums)
-            if dist is not None:
+            if dist is None:
+                ops.reduce_finalize(partials, b, h, w, k, n_sets, sums, cent)
+            else:
+                ops.reduce(partials, b, h, w, k, n_sets, sums)
                 _collective(dist.all_reduce, sums, op=dist.ReduceOp.SUM, group=dist_group)
-            ops.finalize(sums, n_sets, k, cent)
+                ops.finalize(sums, n_sets, k, cent)
 
 
 def shard_rows(height: int, world: int, rank: int, halo: int = 7):

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 8
+#define GCS_ABI_VERSION 9
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -109,6 +109,12 @@ int gcs_kmeans_reduce(const uint64_t *partials_dev, int B, int H, int W, int D, 
 /* SPEC.md §4 update: c = floor((2S + n) / (2n)), empty cluster keeps its centroid. */
 int gcs_kmeans_finalize(const int64_t *sums_dev, int n_sets, int k, int D,
                         uint16_t *centroids_dev, gcs_stream_t stream);
+
+/* Single-rank update: gcs_kmeans_reduce + gcs_kmeans_finalize in ONE launch (no all-reduce needed
+ * in between). sums_dev may be NULL (then only the centroids are written). */
+int gcs_kmeans_reduce_finalize(const uint64_t *partials_dev, int B, int H, int W, int D, int k,
+                               int n_sets, int64_t *sums_dev, uint16_t *centroids_dev,
+                               gcs_stream_t stream);
 
 /* Label slab -> int32 [B][H][W] (the dtype handed to metrics.py:43). */
 int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *out_dev,

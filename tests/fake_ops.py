@@ -74,6 +74,10 @@ class OracleOps:
         new = np.where(cnt > 0, (2 * s[:, :, :-1] + cnt) // np.maximum(2 * cnt, 1), c)
         cent.copy_(torch.from_numpy(new.astype(np.uint16).view(np.int16)))
 
+    def reduce_finalize(self, partials, b, h, w, k, n_sets, sums, cent):
+        self.reduce(partials, b, h, w, k, n_sets, sums)
+        self.finalize(sums, n_sets, k, cent)
+
     def connected_regions(self, labels_i32, out):
         out.copy_(torch.from_numpy(np.stack([so.connected_regions(l) for l in labels_i32.numpy()])))
 

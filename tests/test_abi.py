@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 8
+    assert lib.gcs_abi_version() == 9
 
 
 def test_no_torch_types_in_the_abi():
@@ -109,6 +109,8 @@ def test_device_entry_points_validate_before_launching(lib):
     assert lib.gcs_features_gather(one, 1, 16, 16, 72, 0, one, one, None) == 1
     assert lib.gcs_kmeans_reduce(None, 1, 16, 16, 72, 8, 1, one, None) == 1
     assert lib.gcs_kmeans_finalize(one, 0, 8, 72, one, None) == 1
+    assert lib.gcs_kmeans_reduce_finalize(one, 1, 16, 16, 72, 8, 1, one, None, None) == 1     # no centroids
+    assert lib.gcs_kmeans_reduce_finalize(one, 2, 16, 16, 72, 8, 3, None, one, None) == 1     # n_sets not in {1,B}
     assert lib.gcs_labels_widen(one, 1, 0, 16, one, None) == 1
     assert lib.gcs_features_unpack(one, 1, 16, 16, 0, one, None) == 1
     assert lib.gcs_boundary_counts(one, one, 0, 16, 16, one, one, None) == 1
