@@ -630,7 +630,8 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
-constexpr int KP_PITCH = KP_TP * 2 + 16;  // bytes per plane row (+16: spreads planes over banks)
+constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
+                                          // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
 constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 42 KB LDS, 3 workgroups / CU
 constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 110 KB LDS, 1 workgroup / CU
 

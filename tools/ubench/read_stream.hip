@@ -68,6 +68,41 @@ __global__ __launch_bounds__(256, 3) void stream_c(const v4i *__restrict__ src, 
     if (acc == 0x12345678) out[0] = 1;
 }
 
+// variant D: LDS-DMA (global_load_lds dwordx4) double/triple buffering: NBUF 36 KB buffers per workgroup,
+// NBUF-1 tiles in flight while the current one is "computed"; no VGPR staging, one barrier pair per tile.
+template <int NBUF, int WGS>
+__global__ __launch_bounds__(256, WGS) void stream_d(const v4i *__restrict__ src, int ntiles, int parts, int *out) {
+    extern __shared__ v4i dlds[];                       // NBUF * 2304 chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto dma = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const v4i *g = src + (size_t)tile * 2304 + 256 * i + tid;
+            v4i *l = dlds + buf * 2304 + 256 * i + 64 * wave;        // wave-uniform base; lane*16 implied
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+        }
+    };
+    int acc = 0;
+    int tile = blockIdx.x;
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (tile + d * parts < ntiles) dma(tile + d * parts, d);
+    for (int it = 0; tile < ntiles; tile += parts, ++it) {
+        // wait for the oldest tile only: each wave has 9 DMA instructions per tile in flight
+        if (NBUF >= 4 && tile + 2 * parts < ntiles) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (NBUF >= 3 && tile + parts < ntiles) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int buf = it % NBUF;
+        if (tile + (NBUF - 1) * parts < ntiles) dma(tile + (NBUF - 1) * parts, (it + NBUF - 1) % NBUF);
+        acc ^= dlds[buf * 2304 + (tid * 7) % 2304][0];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (acc == 0x12345678) out[0] = 1;
+}
+
 int main() {
     const size_t bytes = (size_t)64 * 612 * 36864;        // 64 images x 612 tiles x 36 KB (all variants stay inside)
     const size_t n16 = bytes / 16;
@@ -96,6 +131,17 @@ int main() {
     const int ntiles = (int)(bytes / 36864);
     for (int g : {512, 768, 1536})
         { char nm[64]; snprintf(nm, 64, "B: kmeans-like tiles grid=%d", g); time([&] { stream_b<<<g, 256>>>(src, ntiles, g, out); }, nm); }
+    {
+        hipFuncSetAttribute((const void *)stream_d<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 36864);
+        hipFuncSetAttribute((const void *)stream_d<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 36864);
+        hipFuncSetAttribute((const void *)stream_d<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 36864);
+        for (int g : {512, 1024})
+            { char nm[64]; snprintf(nm, 64, "D: LDS-DMA 2 buffers grid=%d", g); time([&] { stream_d<2, 2><<<g, 256, 2 * 36864>>>(src, ntiles, g, out); }, nm); }
+        for (int g : {256, 512})
+            { char nm[64]; snprintf(nm, 64, "D: LDS-DMA 3 buffers grid=%d", g); time([&] { stream_d<3, 1><<<g, 256, 3 * 36864>>>(src, ntiles, g, out); }, nm); }
+        for (int g : {256, 512})
+            { char nm[64]; snprintf(nm, 64, "D: LDS-DMA 4 buffers grid=%d", g); time([&] { stream_d<4, 1><<<g, 256, 4 * 36864>>>(src, ntiles, g, out); }, nm); }
+    }
     {
         const int tpi = 612;   // tiles per 321x488 image
         if ((size_t)64 * tpi * 36864 > bytes) { printf("buffer too small\n"); return 1; }
