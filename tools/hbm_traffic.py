@@ -15,7 +15,7 @@ for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
         key = "gabor_mfma_kernel" if "gabor_mfma_kernel" in n else "kmeans_pass_mfma_kernel" if "kmeans_pass_mfma" in n else \
               "gabor_pad_kernel" if "gabor_pad" in n else None
         if key:
-            acc[(key, n.split("(")[0].split()[-1], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[(key, n.split("(")[0].replace("void ", "").strip(), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for (key, full, grid), cs in sorted(acc.items()):
     f = cs.get("FETCH_SIZE", []); w = cs.get("WRITE_SIZE", [])
