@@ -110,3 +110,31 @@ def test_images_narrower_than_a_kmeans_tile(torch_cuda):
     seg = Segmenter(n_iter=3, k=4)
     got = seg.segment_batch(imgs, mode="global")
     assert np.array_equal(got, so.segment_batch(imgs, mode="global", k=4, n_iter=3))
+
+
+def test_randomised_shapes_banks_and_codebooks(torch_cuda):
+    """40 seeded random cases against the C oracle: image sizes from the 8x8 minimum to a few tiles (odd widths,
+    widths below one Gabor / k-means tile, heights that leave waves idle), banks F = 1..30 with every odd ksize,
+    k = 1..16, n_iter = 1..6, batch 1..5, both codebook modes, connectivity on and off."""
+    from oracle import c_oracle as co
+    from gabor_color_image_segmentation_amd import Segmenter
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        h = int(rng.integers(8, 150))
+        w = int(rng.integers(8, 300)) if case % 3 else int(rng.integers(8, 40))
+        b = int(rng.integers(1, 6))
+        ns, no = int(rng.integers(1, 6)), int(rng.integers(1, 7))
+        ks = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15]))
+        k, n_iter = int(rng.integers(1, 17)), int(rng.integers(1, 7))
+        mode = "global" if rng.integers(0, 2) else "per_image"
+        conn = bool(rng.integers(0, 4) == 0)
+        imgs = _synth(b, h, w, seed=1000 + case)
+        if case % 7 == 0:                                    # hard-edged noise instead of smooth synthetic regions
+            imgs = rng.integers(0, 256, imgs.shape, dtype=np.uint8)
+        seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=n_iter, connectivity=conn)
+        got = seg.segment_batch(imgs, mode=mode)
+        ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, k=k, n_iter=n_iter, mode=mode)
+        if conn:
+            ref = np.stack([so.connected_regions(r) for r in ref])
+        assert np.array_equal(got, ref), dict(case=case, h=h, w=w, b=b, bank=(ns, no, ks), k=k, n_iter=n_iter,
+                                              mode=mode, conn=conn, wrong=float((got != ref).mean()))
