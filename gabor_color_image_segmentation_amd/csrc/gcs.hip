@@ -659,6 +659,15 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
     const int ntiles = pstride / KP_TP;              // plane stride is a whole number of tiles
     const uint16_t *fb = feats + (size_t)b * ntiles * D * KP_TP;   // this image's tiles, each D*256 contiguous
 
+    // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16, stored
+    //      offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D. One coalesced
+    //      read of the K*D centroid block instead of 16 scattered 2-byte global loads per fragment dword.
+    uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
+    for (int i = tid; i < 8 * KT * KP_ROWS; i += KP_TP) {
+        const int j = i / KP_ROWS, d = i % KP_ROWS;
+        cs[i] = (j < K && d < D) ? (uint16_t)(cset[j * D + d] ^ 0x8080u) : (uint16_t)0;
+    }
+    __syncthreads();
     // ---- per-cluster key base (exact int64): 16 * (|c|^2 - 2*(offset terms of the -128 digits)) + j.
     //      key_j = base_j - 32 R0 - 8192 R1 - 2^21 R2 = 16 * score_j + j, so ONE 64-bit minimum yields the
     //      best score and the lowest index on ties. 16 lanes per cluster, folded with lane shuffles.
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         long long nrm = 0, scl = 0, sch = 0;
         if (j < K)
             for (int d = sub; d < D; d += 16) {
-                const long long c = cset[j * D + d];
+                const long long c = cs[j * KP_ROWS + d] ^ 0x8080u;
                 nrm += c * c;
                 scl += c & 255;
                 sch += c >> 8;
@@ -686,37 +695,30 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         }
       }
     }
-    // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
-    if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
     // ---- assign A fragments: row r = 4*jj + pat of tile mt (cluster j = 8*mt + jj);
-    //      k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2, byte t&1)
+    //      k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2, byte t&1): the 8 planes of a fragment are one
+    //      16-byte scratch read. Per plane (u16 w = digits cl | ch << 8) the pattern bytes (byte 0, byte 1) are
+    //      LL = (cl, 0) = w & 0x00ff, M = (ch, cl) = bytes swapped, HH = (0, ch) = w & 0xff00, row 3 = 0.
     v4i apat[KT][KP_DSTEPS];
     {
         const int r = lane & 31, h = lane >> 5;
         const int jj = r >> 2, pat = r & 3;
+        const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
+        const unsigned sel = pat == 1 ? 0x02030001u : 0x03020100u;
 #pragma unroll
-        for (int mt = 0; mt < KT; ++mt) {
-            const int j = 8 * mt + jj;
+        for (int mt = 0; mt < KT; ++mt)
 #pragma unroll
             for (int kk = 0; kk < KP_DSTEPS; ++kk) {
-                v4i f = {0, 0, 0, 0};
+                const v4i w = *reinterpret_cast<const v4i *>(&cs[(8 * mt + jj) * KP_ROWS + 16 * kk + 8 * h]);
+                v4i f;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int d = 16 * kk + 8 * h + (t >> 1), bb = t & 1;
-                    int v = 0;
-                    if (j < K && d < D && pat < 3) {
-                        const int c = cset[j * D + d];
-                        const int cl = (c & 255) - 128, ch = (c >> 8) - 128;
-                        if (pat == 0) v = bb ? 0 : cl;
-                        if (pat == 1) v = bb ? cl : ch;
-                        if (pat == 2) v = bb ? ch : 0;
-                    }
-                    f[t >> 2] |= (v & 255) << (8 * (t & 3));
-                }
+                for (int e = 0; e < 4; ++e) f[e] = (int)(__builtin_amdgcn_perm(0u, (unsigned)w[e], sel) & msk);
                 apat[mt][kk] = f;
             }
-        }
     }
+    __syncthreads();                                   // scratch reads done: the tile buffer is free again
+    // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
+    if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
     v4i accu[KP_NT];
 #pragma unroll
     for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
@@ -863,26 +865,29 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         __syncthreads();
     }
 
-    // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row
-    int *red = reinterpret_cast<int *>(s_tile);               // [16][16 * KP_NT]
-    for (int i = tid; i < 16 * KP_NT * 16; i += KP_TP) red[i] = 0;
-    __syncthreads();
+    // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row: every wave
+    //      parks its registers in its own slice of the tile buffer (no zero-fill, no atomics), one barrier.
+    constexpr int RW = KP_NT * 16;                            // byte-planes per cluster row
+    int *red = reinterpret_cast<int *>(s_tile);               // [KP_TP / 64 waves][16][RW]
+    static_assert((KP_TP / 64) * 16 * RW * 4 <= KP_ROWS * KP_PITCH, "fold buffer exceeds the tile buffer");
 #pragma unroll
     for (int nt = 0; nt < KP_NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&red[(4 * ug + e) * (KP_NT * 16) + 16 * nt + un], accu[nt][e]);
+        for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[nt][e];
     __syncthreads();
     const int D1 = D + 1;
     uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
+    auto folded = [&](int j, int bp) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < KP_TP / 64; ++w) s += red[(w * 16 + j) * RW + bp];
+        return -(long long)s / 128;                           // the one-hot digit is -128
+    };
     for (int i = tid; i < K * D1; i += KP_TP) {
         const int j = i / D1, e = i % D1;
-        const long long nj = -(long long)red[j * (KP_NT * 16) + cnt_bp] / 128;
+        const long long nj = folded(j, cnt_bp);
         long long out = nj;
-        if (e < D) {
-            const long long lo = -(long long)red[j * (KP_NT * 16) + 2 * e] / 128 + 128 * nj;
-            const long long hi = -(long long)red[j * (KP_NT * 16) + 2 * e + 1] / 128 + 128 * nj;
-            out = lo + 256 * hi;
-        }
+        if (e < D) out = (folded(j, 2 * e) + 128 * nj) + 256 * (folded(j, 2 * e + 1) + 128 * nj);
         prow[i] = (uint64_t)out;
     }
 }
