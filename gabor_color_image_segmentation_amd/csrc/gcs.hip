@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     for (int c = 0; c < 3; ++c) {
 #pragma unroll 1
         for (int rb = 0; rb < 2; ++rb) {       // two 4-row blocks per wave
+            if (y0 + wave * 8 + rb * 4 >= H) break;   // block wholly below the image (H = 321: 1 row in the last tile row)
             const int trow = wave * 8 + rb * 4 + lyy;
             unsigned outp[MT][4][4];
 #pragma unroll

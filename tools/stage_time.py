@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the stages of the path for any bank: tools/stage_time.py [B] [n_scales] [n_orient] [k] [mode].
+"""Time the stages of the path for any bank: tools/stage_time.py [B] [n_scales] [n_orient] [k] [mode] [H] [W].
 
 Prints the Gabor stage, one Lloyd pass and the whole segment_device step (n_iter = 10) on B synthetic
 321x481 images, with the algorithmic GB/s of the pass ((2D+1) B/px) and the int8 TOP/s of the bank.
@@ -14,7 +14,8 @@ ns = int(a[1]) if len(a) > 1 else 4
 no = int(a[2]) if len(a) > 2 else 6
 k = int(a[3]) if len(a) > 3 else 8
 mode = a[4] if len(a) > 4 else "global"
-H, W = 321, 481
+H = int(a[5]) if len(a) > 5 else 321
+W = int(a[6]) if len(a) > 6 else 481
 imgs = torch.from_numpy(synthetic_shard(0, B, H, W)).cuda()
 seg = Segmenter(n_scales=ns, n_orient=no, k=k)
 D = seg.bank.n_features
@@ -38,6 +39,6 @@ seg.ops.kmeans_init(ws["feats"], B, H, W, k, n_sets, ws["cent"])
 tp = timed(lambda: seg.ops.assign_accumulate(ws["feats"], ws["cent"], B, H, W, k, n_sets, ws["labels"], ws["partials"]))
 ts = timed(lambda: seg.segment_device(imgs, mode=mode), n=5, warm=1)
 px = B * H * W
-print(f"B={B} bank {ns}x{no} D={D} k={k} {mode}: gabor {tg:.3f} ms ({2*225*4*seg.bank.n_filters*3*px/tg/1e9:.0f} TOP/s, "
+print(f"B={B} {W}x{H} bank {ns}x{no} D={D} k={k} {mode}: gabor {tg:.3f} ms ({2*225*4*seg.bank.n_filters*3*px/tg/1e9:.0f} TOP/s, "
       f"{(3+2*D)*px/tg/1e6:.0f} GB/s) | pass {tp:.3f} ms ({(2*D+1)*px/tp/1e6:.0f} GB/s alg) | "
       f"step {ts:.2f} ms = {px/ts/1e3:.0f} Mpix/s")
