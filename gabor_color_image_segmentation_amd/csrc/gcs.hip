@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[mt][e] = 0;   // inline-constant C of the first MFMA
+                    // the wave inside its MFMA chain outranks the one in its (pure VALU) epilogue: -2.5 % (A/B)
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                     // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter.
                     // All 4*MT magnitudes are computed as independent chains (ILP), then pinned.
                     unsigned mag[MT][4];
