@@ -764,7 +764,11 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         const int tile = phys(ltile);
         stage_write();
         __syncthreads();
+        // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
+        // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
+        __builtin_amdgcn_s_setprio(3);
         if (ltile + parts < ntiles) stage_load(phys(ltile + parts));   // in flight during the MFMAs
+        __builtin_amdgcn_s_setprio(0);
 
         const int pp0 = tile * KP_TP;
         const int x0 = pp0 % pitch;               // column of the tile's first pixel (one modulo per tile)
