@@ -111,8 +111,9 @@ class TimedOps:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps; the MFMA-heavy Gabor kernel needs ~10 steps (35 ms) to reach its steady clock")
     ap.add_argument("--mode", default="global", choices=["global", "per_image"])
     ap.add_argument("--batch", type=int, default=PER_GPU, help="images per GPU")
     ap.add_argument("--n-iter", type=int, default=10)
