@@ -68,10 +68,11 @@ def cpu_baseline(k, n_iter):
 class TimedOps:
     """Wraps HipOps: HIP events (on the launch stream) around the two streaming kernels.
 
-    Every Gabor launch is bracketed; of the Lloyd passes every PASS_STRIDE-th launch is (passes 2 and 7 of
-    each 10-pass step: one forward and one reverse sweep). An event pair costs ~7 us of stream time, and
-    bracketing all 11 launches of a step made the step itself 2 % slower (measured, same box)."""
-    PASS_STRIDE = 5
+    Every Gabor launch is bracketed; of the Lloyd passes every PASS_STRIDE-th launch is (stride 11 against 10
+    passes per step: the sampled position walks through all ten passes, forward and reverse sweeps alike).
+    Each event costs ~5.7 us of stream time (rocprofv3 kernel trace: that is the gap before a kernel that
+    follows a record, 0.0 us otherwise); bracketing all 11 launches of a step made the step 2 % slower."""
+    PASS_STRIDE = 11
 
     def __init__(self, ops, torch):
         self._ops, self._torch = ops, torch
@@ -97,7 +98,7 @@ class TimedOps:
 
     def assign_accumulate(self, *a, **kw):
         self._n_pass += 1
-        if self._n_pass % self.PASS_STRIDE != 3:
+        if self._n_pass % self.PASS_STRIDE != 4:
             return self._ops.assign_accumulate(*a, **kw)
         return self._timed("assign", self._ops.assign_accumulate, *a, **kw)
 

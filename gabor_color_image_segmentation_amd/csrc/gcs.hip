@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__re
     if (e < row_len) {
         const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
         const int to_cnt = (e / D1) * D1 + (D1 - 1) - e;      // offset of this cluster's count column
-#pragma unroll 4
+#pragma unroll 4                                        // (unroll 16 measured 4x slower in the pipeline: 30.9 vs 7.8 us)
         for (int r = slice; r < rows_per_set; r += 16) {
             s += p[(size_t)r * row_len];
             if (FIN) c += p[(size_t)r * row_len + to_cnt];
@@ -1088,14 +1088,16 @@ extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D
     return GCS_OK;
 }
 
-// One block row per image row; a thread widens 4 labels (one aligned dword of the slab: pitch % 8 == 0).
+// Block = 64 x 4 threads: four image rows per block, a thread widens 4 labels (one aligned dword of the slab:
+// pitch % 8 == 0) per step of 64 dwords.
 __global__ __launch_bounds__(256) void widen_kernel_rows(const uint8_t *__restrict__ labels, int H, int W, int pitch,
-                                                         size_t pstride, int row0, int32_t *__restrict__ out) {
-    const int by = row0 + blockIdx.y;                // b*H + y
+                                                         size_t pstride, int rows, int32_t *__restrict__ out) {
+    const int by = blockIdx.x * 4 + threadIdx.y;     // b*H + y
+    if (by >= rows) return;
     const int b = by / H, y = by - b * H;
     const unsigned *src = reinterpret_cast<const unsigned *>(labels + (size_t)b * pstride + (size_t)y * pitch);
     int32_t *dst = out + (size_t)by * W;
-    for (int x4 = blockIdx.x * blockDim.x + threadIdx.x; 4 * x4 < W; x4 += gridDim.x * blockDim.x) {
+    for (int x4 = threadIdx.x; 4 * x4 < W; x4 += 64) {
         const unsigned v = src[x4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1107,12 +1109,9 @@ extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int3
     if (!labels || !out) return fail(GCS_EINVAL, "gcs_labels_widen: NULL pointer");
     if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H > 0x7fffffffLL)
         return fail(GCS_EINVAL, "gcs_labels_widen: bad shape");
-    const int rows = B * H;                          // grid.y is limited to 65535: fold the rest into z-less chunks
-    for (int r0 = 0; r0 < rows; r0 += 65535) {
-        const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        hipLaunchKernelGGL(widen_kernel_rows, dim3((W / 4 + 255) / 256 > 0 ? (W / 4 + 255) / 256 : 1, nr), dim3(256), 0,
-                           stream, labels, H, W, (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), r0, out);
-    }
+    const int rows = B * H;
+    hipLaunchKernelGGL(widen_kernel_rows, dim3((rows + 3) / 4), dim3(64, 4), 0, stream, labels, H, W,
+                       (int)gcs_feature_pitch(W), gcs_feature_plane_stride(H, W), rows, out);
     GCS_CHECK_LAUNCH("gcs_labels_widen");
     return GCS_OK;
 }
