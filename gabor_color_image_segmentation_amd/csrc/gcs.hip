@@ -147,6 +147,14 @@ __device__ __forceinline__ size_t slab_index(size_t image_tile0, int D, int d, i
     return ((image_tile0 + (size_t)(pp / KP_TP)) * D + d) * KP_TP + (pp % KP_TP);
 }
 
+// Partial sums, element-major: [set][element i of k*(D+1)][rows of that set] uint64, rows = the workgroups that
+// contribute to the set (per-image codebooks: the image's `parts`; one codebook: all gridDim.y * parts). The 768
+// values an output element is summed from are then one contiguous 6 KB run for kmeans_reduce_kernel.
+__device__ __forceinline__ size_t partial_index(int per_image, int b, int part, int parts, int i, int row_len) {
+    return per_image ? ((size_t)b * row_len + i) * parts + part
+                     : (size_t)i * ((size_t)gridDim.y * parts) + (size_t)b * parts + part;
+}
+
 // ================================================================================ Gabor
 constexpr int G_TW = 64;            // output tile width  (4 lanes-in-x * 16 shifts)
 constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
@@ -606,11 +614,10 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         }
     }
     __syncthreads();
-    uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
     for (int i = tid; i < K * D1; i += 256) {
         uint64_t s = 0;
         for (int rr = 0; rr < R; ++rr) s += acc[(size_t)i * R + rr];
-        prow[i] = s;
+        partials[partial_index(per_image, b, part, parts, i, K * D1)] = s;
     }
 }
 
@@ -884,7 +891,6 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[nt][e];
     __syncthreads();
     const int D1 = D + 1;
-    uint64_t *prow = partials + ((size_t)b * parts + part) * K * D1;
     auto folded = [&](int j, int bp) {
         int s = 0;
 #pragma unroll
@@ -896,7 +902,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && (N
         const long long nj = folded(j, cnt_bp);
         long long out = nj;
         if (e < D) out = (folded(j, 2 * e) + 128 * nj) + 256 * (folded(j, 2 * e + 1) + 128 * nj);
-        prow[i] = (uint64_t)out;
+        partials[partial_index(per_image, b, part, parts, i, K * D1)] = (uint64_t)out;
     }
 }
 
@@ -990,47 +996,35 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     return fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
 }
 
-// sums[set][e] = sum over the partial rows of the images in this set. Integer sums: any
-// order gives the same bits. Block = 16 elements x 16 row slices, folded through LDS.
-// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in
-// between): every thread also sums the count column of its element's cluster (L2 hits), so no second
-// kernel and no cross-block dependency is needed.
+// sums[set][e] = sum of the set's partial values of element e (one contiguous run, see partial_index). Integer
+// sums: any order gives the same bits. One wave per element: coalesced reads, shuffle fold.
+// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in between): the wave
+// also folds the count element of its cluster, so no second kernel and no cross-block dependency is needed.
 template <bool FIN>
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
                                                             int rows_per_set, int row_len, int D1,
                                                             long long *__restrict__ sums,
                                                             uint16_t *__restrict__ cent) {
-    __shared__ uint64_t s_part[16][17];
-    __shared__ uint64_t s_cnt[16][17];
-    const int set = blockIdx.y;
-    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + el;
+    const int set = blockIdx.y, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= row_len) return;                                  // whole waves leave; no barrier below
+    const int j = e / D1, d = e - j * D1;
+    const uint64_t *p = partials + ((size_t)set * row_len + e) * rows_per_set;
+    const uint64_t *pc = partials + ((size_t)set * row_len + j * D1 + (D1 - 1)) * rows_per_set;
     uint64_t s = 0, c = 0;
-    if (e < row_len) {
-        const uint64_t *p = partials + (size_t)set * rows_per_set * row_len + e;
-        const int to_cnt = (e / D1) * D1 + (D1 - 1) - e;      // offset of this cluster's count column
-#pragma unroll 4                                        // (unroll 16 measured 4x slower in the pipeline: 30.9 vs 7.8 us)
-        for (int r = slice; r < rows_per_set; r += 16) {
-            s += p[(size_t)r * row_len];
-            if (FIN) c += p[(size_t)r * row_len + to_cnt];
-        }
+    for (int r = lane; r < rows_per_set; r += 64) {
+        s += p[r];
+        if (FIN) c += pc[r];
     }
-    s_part[slice][el] = s;
-    if (FIN) s_cnt[slice][el] = c;
-    __syncthreads();
-    if (slice == 0 && e < row_len) {
-        uint64_t t = 0, n = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            t += s_part[i][el];
-            if (FIN) n += s_cnt[i][el];
-        }
-        if (sums) sums[(size_t)set * row_len + e] = (long long)t;
-        if (FIN) {
-            const int j = e / D1, d = e - j * D1, D = D1 - 1;
-            if (d < D && n > 0)
-                cent[((size_t)set * (row_len / D1) + j) * D + d] = (uint16_t)((2 * t + n) / (2 * n));
-        }
+    for (int m = 32; m >= 1; m >>= 1) {
+        s += __shfl_xor(s, m);
+        if (FIN) c += __shfl_xor(c, m);
+    }
+    if (lane == 0) {
+        if (sums) sums[(size_t)set * row_len + e] = (long long)s;
+        if (FIN && d < D1 - 1 && c > 0)
+            cent[((size_t)set * (row_len / D1) + j) * (D1 - 1) + d] = (uint16_t)((2 * s + c) / (2 * c));
     }
 }
 
@@ -1048,7 +1042,7 @@ extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, 
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
+    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
                        rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
     return GCS_OK;
@@ -1061,7 +1055,7 @@ extern "C" int gcs_kmeans_reduce_finalize(const uint64_t *partials, int B, int H
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3((row_len + 15) / 16, n_sets), dim3(256), 0, stream, partials,
+    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
                        rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce_finalize");
     return GCS_OK;
