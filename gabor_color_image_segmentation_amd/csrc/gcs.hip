@@ -3,15 +3,18 @@
 // for this path; the slot filled is /root/reference/BSD_metrics/script.py:30.
 //
 // Kernels
-//   gabor_mfma_kernel   im2col GEMM on v_mfma_i32_32x32x32_i8: A = packed 2-digit int8 taps
-//                       (rows = filter x {re_lo,re_hi,im_lo,im_hi}), B = (pixel-128) windows
-//                       built from an LDS tile by dword reads + v_alignbyte, exact int32
-//                       accumulate, fused epilogue (digit recombine, >>shift, |.|^2, isqrt)
-//                       -> uint16 feature planes.
-//   kmeans_assign_kernel exact integer argmin via fp32 byte-digit FMAs (all partial sums
-//                       < 2^24, hence exact), LDS-replicated u32 accumulators, per-workgroup
-//                       partial slabs (no global atomics, deterministic).
-//   kmeans_reduce / finalize / init / unpack / widen: small helpers.
+//   gabor_pad_kernel         interleaved RGB -> planar (pixel - 128) with the reflect border materialised.
+//   gabor_mfma_kernel        im2col GEMM on v_mfma_i32_32x32x32_i8: A = packed 2-digit int8 taps (rows = filter x
+//                            {re_lo,re_hi,im_lo,im_hi}, resident in registers), B = (pixel-128) windows built from
+//                            an LDS tile (LDS-DMA double buffer) by dword reads + v_alignbit, exact int32 accumulate,
+//                            fused epilogue (digit recombine, >>shift, |.|^2, exact isqrt) -> tile-major u16 slab.
+//   kmeans_pass_mfma_kernel  one Lloyd pass (assign + update) on the matrix cores for D <= 207; HBM-bound stream.
+//   kmeans_assign_kernel     generic pass for D >= 208: exact integer argmin via fp32 byte-digit FMAs (all partial
+//                            sums < 2^24, hence exact), LDS-replicated u32 accumulators.
+//   kmeans_reduce_kernel     element-major partial sums -> int64 sums (+ the centroid update when single-rank).
+//   kmeans_finalize / init / features_gather / unpack / widen: small helpers.
+//   boundary_* , cc_*        boundary recall/precision counts (metrics.py:58-96) and connected regions (SPEC.md 7).
+// Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -169,7 +172,7 @@ __device__ __forceinline__ int reflect_clamp(int i, int n) {
     return min(max(i, 0), n - 1); // only reached for pixels whose outputs are not stored
 }
 
-// floor(sqrt(n)) for n <= 2 * 32642^2 < 2^31 (SPEC.md §3 bound), exact, in 8 cheap VALU ops
+// floor(sqrt(n)) for n <= 2 * 32642^2 < 2^31 (SPEC.md §3 bound), exact, in 7 VALU ops
 // (measured on gfx950, tools/ubench/valu_ops2: v_cvt_u32_f32 ~3 ns and v_cmp+v_addc ~4.3 ns per
 // wave-instruction, against ~1.2 ns for an add):
 //   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
@@ -212,9 +215,7 @@ __global__ __launch_bounds__(256) void gabor_pad_kernel(const uint8_t *__restric
 #ifndef GCS_GABOR_WAVES
 #define GCS_GABOR_WAVES 2
 #endif
-#ifndef GCS_GABOR_MTMAX
-#define GCS_GABOR_MTMAX 2
-#endif
+constexpr int GCS_GABOR_MTMAX = 2;   // row tiles per launch: 3 needs ~250 VGPRs at 2 waves/SIMD and spills (measured slower)
 template <int MT, bool FULLF>   // FULLF: n_filters is a multiple of 8 -> no per-filter store guard
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int H, int Hp, int Wp, const int8_t *__restrict__ apack,
@@ -417,8 +418,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, FF_>), grid, block, 0, stream, planes, H, Hp, Wp, packed, bias, mt0, \
                        F, shift, feats, pitch, pstride, tiles_x, tiles_per_image, total_tiles)
         const bool fullf = (F % 8) == 0;
-        if (n == 3) { if (fullf) GCS_GABOR_LAUNCH(3, true); else GCS_GABOR_LAUNCH(3, false); }
-        else if (n == 2) { if (fullf) GCS_GABOR_LAUNCH(2, true); else GCS_GABOR_LAUNCH(2, false); }
+        if (n == 2) { if (fullf) GCS_GABOR_LAUNCH(2, true); else GCS_GABOR_LAUNCH(2, false); }
         else { if (fullf) GCS_GABOR_LAUNCH(1, true); else GCS_GABOR_LAUNCH(1, false); }
 #undef GCS_GABOR_LAUNCH
         GCS_CHECK_LAUNCH("gcs_gabor_features");
@@ -643,8 +643,8 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
 
 constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
                                           // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
-constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 42 KB LDS, 3 workgroups / CU
-constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 110 KB LDS, 1 workgroup / CU
+constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 46 KB LDS, 3 workgroups / CU
+constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 120 KB LDS, 1 workgroup / CU
 
 #ifndef GCS_KP_WAVES
 #define GCS_KP_WAVES 3
