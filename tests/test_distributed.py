@@ -116,3 +116,34 @@ def test_config5_size_2048_sharded_equals_unsharded_on_gpu(tmp_path):
     ref = Segmenter(n_iter=4).segment_batch(synthetic_batch(1, height, width, seed=41), mode="global")
     assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.uint8))
     assert len(np.unique(ref)) > 1
+
+
+def _rccl_worker(rank, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from gabor_color_image_segmentation_amd.segmenter import _collective
+    sums = (torch.arange(8 * 73, dtype=torch.int64, device=dev).view(1, 8, 73) + 1) * ((1 << 55) + 12345)
+    keep = sums.clone()
+    _collective(dist.all_reduce, sums, op=dist.ReduceOp.SUM)          # what lloyd() does between reduce and finalize
+    cent = (torch.arange(8 * 72, dtype=torch.int32, device=dev) * 113).to(torch.int16).view(1, 8, 72)
+    keep_c = cent.clone()
+    _collective(dist.broadcast, cent.view(torch.uint8), src=0)         # the init-centroid broadcast
+    dist.barrier()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(sums, keep)) and bool(torch.equal(cent, keep_c))
+    open(os.path.join(tmp, "rccl_ok"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_carries_the_collective_dtypes(tmp_path):
+    """The N > 1 GPU path uses exactly two collectives: all_reduce(SUM) of an int64 tensor (values beyond 2^53,
+    so a detour through floating point would show) and broadcast of the int16 centroids viewed as bytes. A
+    one-rank RCCL group on cuda:0 checks that this RCCL build initialises here and accepts both."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "rccl_ok").read() == "1"
