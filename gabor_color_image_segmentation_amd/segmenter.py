@@ -152,7 +152,7 @@ def _collective(fn, t, **kw):
 
 
 def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None,
-          rows=None, init=None):
+          rows=None, init=None, force_collectives=False):
     """SPEC.md §4 schedule on one feature slab. ``mode``: 'per_image' or 'global'.
 
     In 'global' mode with torch.distributed initialised, the init centroids come from
@@ -160,12 +160,14 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
     (RCCL on GPU, any order: integer sums are exact). One collective per Lloyd pass.
     ``rows=(lo, hi)``: only these rows of every image vote (row-sharded images, halo rows
     excluded); ``init(cent)``: custom centroid initialisation (row-sharded images).
+    ``force_collectives``: take the multi-rank branch (reduce, all-reduce, finalize) even in a one-rank
+    group, so that a single GPU can exercise the RCCL path end to end (tests).
     """
     n_sets = b if mode == "per_image" else 1
     dist = None
     if mode == "global":
         import torch.distributed as td
-        if td.is_available() and td.is_initialized() and td.get_world_size(dist_group) > 1:
+        if td.is_available() and td.is_initialized() and (td.get_world_size(dist_group) > 1 or force_collectives):
             dist = td
     if init is not None:
         init(cent)
@@ -206,6 +208,7 @@ class Segmenter:
         if n_iter < 1:
             raise ValueError("n_iter must be >= 1")
         self.k, self.n_iter = int(k), int(n_iter)
+        self.force_collectives = False     # tests: run the multi-rank branch of lloyd() in a one-rank group
         self.connectivity = bool(connectivity)     # SPEC.md §7 post-pass
         self.bank = make_bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
         self.ops = ops if ops is not None else HipOps(self.bank, device)
@@ -250,7 +253,7 @@ class Segmenter:
             ws = self._workspace(n, h, w, mode) if n == g else self._tail_workspace(n, h, w, mode)
             self.ops.gabor_features(imgs[g0:g0 + n], ws["feats"])
             lloyd(self.ops, ws["feats"], n, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
-                  ws["cent"], ws["sums"], dist_group)
+                  ws["cent"], ws["sums"], dist_group, force_collectives=self.force_collectives)
             self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
         if self.connectivity:
             regions = torch.empty_like(out)

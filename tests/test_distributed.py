@@ -135,6 +135,16 @@ def _rccl_worker(rank, port, tmp):
     dist.barrier()
     torch.cuda.synchronize()
     ok = bool(torch.equal(sums, keep)) and bool(torch.equal(cent, keep_c))
+    # the whole multi-rank branch of lloyd() (reduce kernel -> RCCL all-reduce -> finalize kernel, init broadcast)
+    # on this one GPU: kernels on torch's current stream, RCCL on its own stream, ordered by torch's events
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    from oracle import spec_oracle as so
+    imgs = synthetic_batch(3, 72, 104, seed=21)
+    seg = Segmenter(k=6, n_iter=5, device="cuda:0")
+    seg.force_collectives = True
+    got = seg.segment_device(torch.from_numpy(imgs).to(dev), mode="global").cpu().numpy()
+    ok = ok and bool(np.array_equal(got, so.segment_batch(imgs, mode="global", k=6, n_iter=5)))
     open(os.path.join(tmp, "rccl_ok"), "w").write("1" if ok else "0")
     dist.destroy_process_group()
 
@@ -143,7 +153,8 @@ def _rccl_worker(rank, port, tmp):
 def test_rccl_carries_the_collective_dtypes(tmp_path):
     """The N > 1 GPU path uses exactly two collectives: all_reduce(SUM) of an int64 tensor (values beyond 2^53,
     so a detour through floating point would show) and broadcast of the int16 centroids viewed as bytes. A
-    one-rank RCCL group on cuda:0 checks that this RCCL build initialises here and accepts both."""
+    one-rank RCCL group on cuda:0 checks that this RCCL build initialises here and accepts both, then runs the whole
+    multi-rank branch of lloyd() through RCCL against the oracle."""
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / "rccl_ok").read() == "1"
