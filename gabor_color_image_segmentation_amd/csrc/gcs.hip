@@ -1314,3 +1314,66 @@ extern "C" int gcs_connected_regions(const int32_t *labels, int B, int H, int W,
     GCS_CHECK_LAUNCH("gcs_connected_regions");
     return GCS_OK;
 }
+
+// ======================================================================= region tables (§8f-2)
+// Integer part of /root/reference/BSD_metrics/metrics.py:102-146 (label x annotator contingency table and region
+// areas) and :160-181 (4-neighbour perimeter: image-border pixels, or pixels with a different 4-neighbour). One
+// thread per pixel; workgroup-private tables in LDS when they fit (k-means label maps: a few clusters, every
+// atomic on a handful of addresses), global atomics otherwise (connected regions: thousands of sparse rows).
+__global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__restrict__ labels,
+                                                            const uint16_t *__restrict__ truth, int A, int H, int W,
+                                                            int n_seg, int stride, int use_lds,
+                                                            unsigned *__restrict__ hist, unsigned *__restrict__ area,
+                                                            unsigned *__restrict__ perim) {
+    extern __shared__ unsigned s_tab[];                        // [A][n_seg][stride] hist | [n_seg] area | [n_seg] perim
+    const int n_hist = A * n_seg * stride, n_tab = n_hist + 2 * n_seg;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = 0u;
+        __syncthreads();
+    }
+    unsigned *t_hist = use_lds ? s_tab : hist, *t_area = use_lds ? s_tab + n_hist : area,
+             *t_perim = use_lds ? s_tab + n_hist + n_seg : perim;
+    const int P = H * W;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int l = labels[p];
+        if ((unsigned)l >= (unsigned)n_seg) continue;          // caller passes n_seg = max + 1; never index outside
+        const int y = p / W, x = p - y * W;
+        bool edge = y == 0 || y == H - 1 || x == 0 || x == W - 1;
+        if (!edge) edge = labels[p - W] != l || labels[p + W] != l || labels[p - 1] != l || labels[p + 1] != l;
+        atomicAdd(&t_area[l], 1u);
+        if (edge) atomicAdd(&t_perim[l], 1u);
+        for (int a = 0; a < A; ++a) {
+            const int t = truth[(size_t)a * P + p];
+            if (t < stride) atomicAdd(&t_hist[((size_t)a * n_seg + l) * stride + t], 1u);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_tab; i += blockDim.x) {
+            const unsigned v = s_tab[i];
+            if (v) atomicAdd(i < n_hist ? &hist[i] : i < n_hist + n_seg ? &area[i - n_hist] : &perim[i - n_hist - n_seg], v);
+        }
+    }
+}
+
+extern "C" int gcs_region_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, int n_segments,
+                                 int n_truth_labels, uint32_t *hist, uint32_t *area, uint32_t *perim,
+                                 gcs_stream_t stream) {
+    if (!labels || !truth || !hist || !area || !perim) return fail(GCS_EINVAL, "gcs_region_counts: NULL pointer");
+    if (A <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || n_segments <= 0 || n_truth_labels <= 0 ||
+        (long long)A * n_segments * n_truth_labels > 0x3fffffffLL)
+        return fail(GCS_EINVAL, "gcs_region_counts: bad shape");
+    const size_t n_hist = (size_t)A * n_segments * n_truth_labels;
+    hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)n_segments * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)n_segments * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return hip_fail(e, "gcs_region_counts(memset)");
+    const size_t lds = (n_hist + 2 * (size_t)n_segments) * sizeof(unsigned);
+    const int use_lds = lds <= 48 * 1024;
+    const int P = H * W;
+    const int blocks = use_lds ? min(256, (P + 1023) / 1024) : min(2048, (P + 255) / 256);
+    hipLaunchKernelGGL(region_counts_kernel, dim3(blocks), dim3(256), use_lds ? lds : 0, stream, labels, truth, A, H, W,
+                       n_segments, n_truth_labels, use_lds, hist, area, perim);
+    GCS_CHECK_LAUNCH("gcs_region_counts");
+    return GCS_OK;
+}

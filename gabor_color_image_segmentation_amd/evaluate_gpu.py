@@ -1,4 +1,5 @@
-"""Boundary recall / precision / F on the GPU.
+"""Scoring on the GPU: boundary recall / precision / F and the region metrics
+(undersegmentation, compactness, density: §8f rank 2).
 
 Same quantities as ``evaluate.metrics.set_boundary_recall/precision`` — i.e. as
 /root/reference/BSD_metrics/metrics.py:58-96 — with the stencils and the masked sums done by
@@ -9,6 +10,8 @@ batches be scored without a device->host round trip of the label maps.
 from __future__ import annotations
 
 import numpy as np
+
+from math import pi
 
 from . import _lib
 
@@ -57,3 +60,77 @@ def boundary_scores_device(labels, segments_truth) -> dict:
     t = np.stack([np.asarray(s).astype(np.uint16) for s in segments_truth]).view(np.int16)
     truths = torch.from_numpy(np.ascontiguousarray(t)).to(labels.device)
     return scores_from_counts(boundary_counts_device(labels, truths))
+
+
+def _truth_stack(segments_truth, device):
+    import torch
+    t = np.stack([np.asarray(s).astype(np.uint16) for s in segments_truth])
+    return t, torch.from_numpy(np.ascontiguousarray(t.view(np.int16))).to(device)
+
+
+def region_counts_device(labels, truths, n_segments, n_truth_labels):
+    """labels: (H,W) int32 device tensor with values < n_segments; truths: (A,H,W) 16-bit device tensor with
+    values < n_truth_labels. Returns host arrays (hist [A,n_segments,n_truth_labels], area, perimeters)."""
+    import torch
+    lib = _lib.load()
+    if labels.dtype != torch.int32 or labels.dim() != 2:
+        raise ValueError("labels must be an (H,W) int32 tensor")
+    if truths.dim() != 3 or truths.shape[1:] != labels.shape or truths.element_size() != 2:
+        raise ValueError("truths must be an (A,H,W) 16-bit tensor matching labels")
+    a, h, w = truths.shape
+    labels, truths = labels.contiguous(), truths.contiguous()
+    hist = torch.empty((a, n_segments, n_truth_labels), dtype=torch.int32, device=labels.device)
+    area = torch.empty(n_segments, dtype=torch.int32, device=labels.device)
+    perim = torch.empty(n_segments, dtype=torch.int32, device=labels.device)
+    _lib.check(lib.gcs_region_counts(labels.data_ptr(), truths.data_ptr(), a, h, w, int(n_segments),
+                                     int(n_truth_labels), hist.data_ptr(), area.data_ptr(), perim.data_ptr(),
+                                     torch.cuda.current_stream(labels.device).cuda_stream), "gcs_region_counts")
+    return hist.cpu().numpy(), area.cpu().numpy(), perim.cpu().numpy()
+
+
+def region_scores_from_counts(hist, area, perim, n_truth, nx, ny) -> dict:
+    """metrics.py:128-146 and :188-201 arithmetic on the integer tables, in the reference's order.
+    ``n_truth[a]`` = max(truth_a) + 1 (metrics.py:116): only those columns of annotator a exist there."""
+    n_seg = len(area)
+    area_f = area.astype(np.float64)
+    under = 0.
+    under_np = 0.
+    for a in range(hist.shape[0]):
+        h = hist[a][:, :int(n_truth[a])].astype(np.float64)
+        u = 0.
+        for k in range(n_seg):                                   # metrics.py:129-130 (integer-valued, exact)
+            u += area_f[k] - np.max(h[k, :])
+        u /= nx * ny
+        under += u
+        unp = float(np.sum(np.minimum(h, h.sum(axis=1)[:, None] - h)))   # metrics.py:137-139: integers, any order
+        unp /= nx * ny
+        under_np += unp
+    under /= hist.shape[0]
+    under_np /= hist.shape[0]
+    compactness = 0
+    max_area = float(nx * ny)
+    for i in range(n_seg):                                       # metrics.py:194-201, same operation order
+        a_i = np.int64(area[i])
+        perimeter = np.float64(perim[i])
+        ratio = a_i / max_area
+        if perimeter > 0:
+            compactness += 4 * pi * ratio * a_i / pow(perimeter, 2)
+    return {"underseg": under, "undersegNP": under_np, "compactness": compactness}
+
+
+def all_scores_device(labels, segments_truth) -> dict:
+    """Every number of ``evaluate.metrics.get_metrics()`` (= metrics.py:246-255 plus F) for a device label map:
+    stencils, masked sums and histograms on the GPU, the reference's float arithmetic on the host."""
+    if len(segments_truth) == 0:
+        raise ZeroDivisionError("no annotator maps (metrics.py:74 divides by len(img_truth))")
+    t, truths = _truth_stack(segments_truth, labels.device)
+    nx, ny = labels.shape
+    n_segments = int(labels.max().item()) + 1                    # metrics.py:51
+    n_truth = [int(s.max()) + 1 for s in t]                      # metrics.py:116
+    counts = boundary_counts_device(labels, truths)
+    out = {"regions": n_segments}
+    out.update(scores_from_counts(counts))
+    hist, area, perim = region_counts_device(labels, truths, n_segments, max(n_truth))
+    out.update(region_scores_from_counts(hist, area, perim, n_truth, nx, ny))
+    out["density"] = float(counts[0]) / float(nx * ny)           # metrics.py:157
+    return out

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 9
+#define GCS_ABI_VERSION 10
 #define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16     /* clusters */
 
@@ -132,6 +132,18 @@ int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *ou
 size_t gcs_boundary_scratch_bytes(int A, int H, int W);
 int gcs_boundary_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
                         void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
+
+/* ---- region tables of one image ------------------------------------------ */
+
+/* Integer part of /root/reference/BSD_metrics/metrics.py:102-146 (undersegmentation: the label x annotator
+ * contingency table `hist` and the region areas) and :160-201 (compactness: the 4-neighbour `perimeters`).
+ * labels_dev int32 [H][W] with values in [0, n_segments) (metrics.py:51: n_segments = max + 1); truth_dev
+ * uint16 [A][H][W] with values < n_truth_labels (the largest `max(truth) + 1` over the annotators,
+ * metrics.py:116). Writes hist_dev uint32 [A][n_segments][n_truth_labels], area_dev and perim_dev uint32
+ * [n_segments] (zeroed here). The caller does the reference's float arithmetic in the reference's order. */
+int gcs_region_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
+                      int n_segments, int n_truth_labels, uint32_t *hist_dev, uint32_t *area_dev,
+                      uint32_t *perim_dev, gcs_stream_t stream);
 
 /* ---- connected regions (SPEC.md §7) -------------------------------------- */
 

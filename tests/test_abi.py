@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 9
+    assert lib.gcs_abi_version() == 10
 
 
 def test_no_torch_types_in_the_abi():
@@ -115,6 +115,8 @@ def test_device_entry_points_validate_before_launching(lib):
     assert lib.gcs_features_unpack(one, 1, 16, 16, 0, one, None) == 1
     assert lib.gcs_boundary_counts(one, one, 0, 16, 16, one, one, None) == 1
     assert lib.gcs_connected_regions(one, 0, 16, 16, one, one, None) == 1
+    assert lib.gcs_region_counts(one, one, 0, 16, 16, 8, 4, one, one, one, None) == 1         # no annotators
+    assert lib.gcs_region_counts(one, one, 2, 16, 16, 0, 4, one, one, one, None) == 1         # no segments
     assert lib.gcs_connected_scratch_bytes(2, 10, 12) == 2 * 2 * 10 * 12 * 4
     assert lib.gcs_boundary_scratch_bytes(5, 321, 481) == 6 * 321 * 481
     assert len(lib.gcs_last_error()) > 0
