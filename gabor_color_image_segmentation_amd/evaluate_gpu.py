@@ -115,7 +115,7 @@ def region_scores_from_counts(hist, area, perim, n_truth, nx, ny) -> dict:
         ratio = a_i / max_area
         if perimeter > 0:
             compactness += 4 * pi * ratio * a_i / pow(perimeter, 2)
-    return {"underseg": under, "undersegNP": under_np, "compactness": compactness}
+    return {"underseg": float(under), "undersegNP": float(under_np), "compactness": float(compactness)}
 
 
 def all_scores_device(labels, segments_truth) -> dict:
