@@ -75,7 +75,7 @@ def test_row_sharded_image_equals_unsharded_oracle(tmp_path, world):
 
 
 @pytest.mark.gpu
-def test_row_sharded_image_on_gpu_two_ranks(tmp_path):
+def test_row_sharded_image_on_gpu_two_ranks(tmp_path, built):
     """Same, through the HIP kernels: two processes share cuda:0, gloo carries the tiny collectives."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import c_oracle as co, spec_oracle as so
@@ -104,7 +104,7 @@ def _big_strip_worker(rank, world, port, height, width, tmp):
 
 
 @pytest.mark.gpu
-def test_config5_size_2048_sharded_equals_unsharded_on_gpu(tmp_path):
+def test_config5_size_2048_sharded_equals_unsharded_on_gpu(tmp_path, built):
     """BASELINE config 5's real tile size: one 2048x2048 image, 2 row strips with halo == the unsharded GPU result
     (the unsharded path itself is pinned to the oracle at smaller sizes)."""
     from gabor_color_image_segmentation_amd import Segmenter
@@ -150,7 +150,7 @@ def _rccl_worker(rank, port, tmp):
 
 
 @pytest.mark.gpu
-def test_rccl_carries_the_collective_dtypes(tmp_path):
+def test_rccl_carries_the_collective_dtypes(tmp_path, built):
     """The N > 1 GPU path uses exactly two collectives: all_reduce(SUM) of an int64 tensor (values beyond 2^53,
     so a detour through floating point would show) and broadcast of the int16 centroids viewed as bytes. A
     one-rank RCCL group on cuda:0 checks that this RCCL build initialises here and accepts both, then runs the whole
