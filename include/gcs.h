@@ -58,7 +58,8 @@ size_t gcs_feature_pitch(int W);
 size_t gcs_feature_plane_stride(int H, int W);
 size_t gcs_feature_slab_bytes(int B, int H, int W, int D);
 size_t gcs_label_slab_bytes(int B, int H, int W); /* uint8 [B][plane_stride] */
-/* uint64 partial-sum rows written by one assign pass: [B][parts][k][D+1]. */
+/* uint64 partial sums written by one assign pass: B * parts * k * (D+1) values, one per k-means workgroup and
+ * output element (element-major; opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */
 size_t gcs_kmeans_parts_per_image(int B, int H, int W);
 size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 
@@ -94,7 +95,9 @@ int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int D, i
  * a row-sharded image are labelled but do not vote. `reverse` != 0 sweeps the slab back to front:
  * alternate it from pass to pass so that each pass starts on what the previous one left in the
  * Infinity Cache (results do not depend on it). labels_dev: label slab; partials_dev:
- * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). */
+ * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). D <= 207 (every BASELINE bank) runs on
+ * the matrix cores, wider feature vectors on a generic VALU pass; k <= GCS_K_MAX. The same n_sets must be passed
+ * to the reduce call that follows (it selects the partial layout). */
 int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
                                  int H, int W, int D, int k, int n_sets, int row_lo, int row_hi,
                                  int reverse, uint8_t *labels_dev, uint64_t *partials_dev,
