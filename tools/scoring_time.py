@@ -1,0 +1,24 @@
+import sys, time, numpy as np, torch, os
+sys.path.insert(0, "/root/repo")
+from gabor_color_image_segmentation_amd import Segmenter
+from gabor_color_image_segmentation_amd.evaluate import metrics
+from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_device
+inp = np.load("/root/repo/tests/golden/bsd_inputs.npz")
+i = "100080"
+segs = [inp["seg_%s_%d" % (i, a)] for a in range(int(inp["nseg_" + i]))]
+img = inp["img_" + i]
+seg = Segmenter()
+d = torch.from_numpy(img[None]).cuda()
+lab = seg.segment_device(d)[0]
+for _ in range(3): all_scores_device(lab, segs)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(20): all_scores_device(lab, segs)
+torch.cuda.synchronize(); print("GPU all_scores_device: %.2f ms per image (%d annotators)" % ((time.perf_counter() - t) / 20 * 1e3, len(segs)))
+labh = lab.cpu().numpy()
+t = time.perf_counter()
+for _ in range(5):
+    m = metrics(img, labh, segs); m.set_metrics()
+print("host mirror (vectorised numpy/scipy): %.2f ms per image" % ((time.perf_counter() - t) / 5 * 1e3))
+t = time.perf_counter()
+for _ in range(20): seg.segment_device(d)
+torch.cuda.synchronize(); print("segment_device: %.2f ms" % ((time.perf_counter() - t) / 20 * 1e3))
