@@ -276,7 +276,14 @@ def main():
                                 codebook=args.mode, global_batch=world * B, features="uint16 Q7",
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"
                                 if args.mode == "global" else f"dp{world} (independent images)"),
-                    roofline=roofline, cpu_baseline=cpu, kernels=kernels, **extra)
+                    roofline=roofline, cpu_baseline=cpu, kernels=kernels,
+                    # whole job against the HBM roof, un-fused definition of SURVEY.md §8d with the uint16 feature
+                    # denominators: (3 + 2D) + n_iter * (2D + 1) bytes per pixel, per GPU
+                    end_to_end=dict(alg_bytes_per_px=(3 + 2 * D) + args.n_iter * (2 * D + 1),
+                                    gbs_per_gpu=round(((3 + 2 * D) + args.n_iter * (2 * D + 1)) * px * args.steps / dt / 1e9, 1),
+                                    hbm_frac=round(((3 + 2 * D) + args.n_iter * (2 * D + 1)) * px * args.steps / dt / 1e9
+                                                   / HBM_PEAK_GBS, 4)),
+                    **extra)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
