@@ -4,7 +4,7 @@
  * loops; oracle/spec_oracle.py uses scipy.ndimage instead). PARITY UNPINNED against the
  * reference: /root/reference holds no Gabor or k-means code to restate (the
  * slot is /root/reference/BSD_metrics/script.py:30). Pinned only against spec_oracle.py
- * (tests/test_c_oracle.py) and the committed fixtures in tests/golden/.
+ * (tests/test_oracle.py) and the committed fixtures in tests/golden/.
  *
  * Build: make -C oracle   (gcc -O2 -shared -> oracle/_build/liboracle.so)
  */
