@@ -8,4 +8,5 @@ export PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg
 (cd $HERE/../.. && python $HERE/make_path_golden.py)
 (cd $REF && /opt/conda/bin/python3.9 -W ignore $HERE/make_scoring_golden.py $HERE)
 (cd $HERE && /opt/conda/bin/python3.9 -W ignore $HERE/make_bank_golden.py $HERE)
+(cd $HERE && /opt/conda/bin/python3.9 -W ignore $HERE/make_feature_golden.py $HERE)
 ls -la $HERE

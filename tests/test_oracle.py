@@ -143,3 +143,24 @@ def test_integer_kmeans_tracks_scikit_learn_lloyd():
     assert km.n_iter_ == 9
     assert (km.labels_ == g["labels_" + i].ravel()).mean() > 0.995
     assert np.abs(km.cluster_centers_ - g["centroids_" + i]).max() < 4.0
+
+
+def test_features_are_the_scikit_image_gabor_filter_magnitude():
+    """The feature stage against a published implementation: skimage.filters.gabor (convolution with its own
+    gabor_kernel, mode='reflect') on a crop of a BSD fixture, red channel, the 12 filters of the two finest scales
+    (fixture from tests/golden/make_feature_golden.py). SPEC.md's features are that magnitude divided by the
+    unit-DC gain, up to the 15x15 truncation (skimage cuts at 3 sigma) and the Q7 fixed-point rounding: within
+    0.05 grey level at the finest scale, 0.2 at the next (magnitudes reach 14.6)."""
+    import math
+    z = np.load(os.path.join(GOLD, "features_skimage.npz"))
+    tapq, shift = so.bank()
+    feats = so.gabor_features(z["crop"], tapq, shift)[:12].astype(np.float64) / 128.0     # channel 0, Q7 -> grey levels
+    kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * 3.0
+    dy, dx = np.mgrid[-7:8, -7:8]
+    for f in range(12):
+        sigma = kappa / (0.4 / math.sqrt(2.0) ** (f // 6))
+        gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
+        ref = z["magnitude"][f].astype(np.float64) / gain
+        assert ref.max() > 5.0
+        assert np.abs(feats[f] - ref).max() < (0.05 if f < 6 else 0.2), f
+    assert np.array_equal(feats * 128.0, co.gabor_features(z["crop"], tapq, shift)[:12])   # and the C oracle agrees
