@@ -1,4 +1,4 @@
-"""Gabor filter bank in fixed point (SPEC.md §2).
+"""Gabor filter bank in fixed point on an octave pyramid (SPEC.md §2).
 
 The reference ships no Gabor code; this is the build-authored
 bank that fills the segmenter slot at /root/reference/BSD_metrics/script.py:30.
@@ -13,6 +13,7 @@ import math
 import numpy as np
 
 KSIZE_MAX = 15          # the HIP kernel's tap frame is 15 rows x 16 columns
+N_SCALES_MAX = 8        # octave pyramid of at most 4 levels (scales 2L, 2L+1 run on level L)
 TAPQ_MAX = 32639        # 127*256 + 127: largest value two signed byte digits hold
 FEATURE_Q = 7           # features are Q7 grey levels
 
@@ -38,6 +39,11 @@ class GaborBank:
     def n_features(self) -> int:
         return 3 * self.n_filters
 
+    @property
+    def n_levels(self) -> int:
+        """Pyramid levels the bank spans (SPEC.md §2): scales 2L and 2L+1 run on level L."""
+        return (self.n_scales + 1) // 2
+
 
 def gabor_taps(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0),
                bandwidth=1.0) -> np.ndarray:
@@ -46,13 +52,15 @@ def gabor_taps(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0)
         raise ValueError(f"ksize must be odd and <= {KSIZE_MAX}, got {ksize}")
     if n_scales < 1 or n_orient < 1:
         raise ValueError("n_scales and n_orient must be >= 1")
+    if n_scales > N_SCALES_MAX:
+        raise ValueError(f"n_scales must be <= {N_SCALES_MAX} (4 pyramid levels)")
     r = (ksize - 1) // 2
     dy, dx = np.mgrid[-r:r + 1, -r:r + 1].astype(np.float64)
     kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * \
         (2.0 ** bandwidth + 1.0) / (2.0 ** bandwidth - 1.0)
     taps = np.empty((n_scales * n_orient, 2, ksize, ksize), np.float64)
     for s in range(n_scales):
-        freq = f_max / ratio ** s
+        freq = f_max / ratio ** s * 2.0 ** (s // 2)      # f_base: cycles per pixel of pyramid level s // 2
         sigma = kappa / freq
         env = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma))
         env /= env.sum()

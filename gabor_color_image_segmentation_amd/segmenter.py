@@ -190,11 +190,17 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
                 ops.finalize(sums, n_sets, k, cent)
 
 
-def shard_rows(height: int, world: int, rank: int, halo: int = 7):
-    """Row strip of rank ``rank``: owned global rows [r0, r1) and the strip [s0, s1) that also
-    carries up to ``halo`` real neighbour rows on interior edges (BASELINE config 5)."""
-    r0 = (height * rank) // world
-    r1 = (height * (rank + 1)) // world
+def shard_rows(height: int, world: int, rank: int, n_levels: int = 2):
+    """Row strip of rank ``rank``: owned global rows [r0, r1) and the strip [s0, s1) that also carries real
+    neighbour rows on interior edges (BASELINE config 5).
+
+    ``n_levels`` = pyramid levels of the bank (SPEC.md §2; 2 for the default 4-scale bank). Strip and ownership
+    boundaries are multiples of ``2**(n_levels-1)`` so that every strip's pyramid is a window of the global
+    pyramid, and the halo is the reach of the coarsest level's 15x15 kernel: ``7 * 2**(n_levels-1)`` rows."""
+    align = 1 << (n_levels - 1)
+    halo = 7 * align
+    r0 = (height * rank) // world // align * align
+    r1 = height if rank == world - 1 else (height * (rank + 1)) // world // align * align
     return r0, r1, max(0, r0 - halo), min(height, r1 + halo)
 
 
@@ -284,6 +290,11 @@ class Segmenter:
             raise ValueError("strips must be at least 8x8 (including halo)")
         if not (s0 <= r0 < r1 <= s0 + hs <= height):
             raise ValueError("inconsistent strip geometry")
+        align = 1 << (self.bank.n_levels - 1)
+        if s0 % align or r0 % align or (r1 % align and r1 != height) or ((s0 + hs) % align and s0 + hs != height):
+            raise ValueError(f"strip boundaries must be multiples of {align} rows (pyramid alignment; use shard_rows)")
+        if (r0 - s0 < 7 * align and s0 > 0) or (s0 + hs - r1 < 7 * align and s0 + hs < height):
+            raise ValueError(f"interior strip edges need {7 * align} halo rows (use shard_rows)")
         ws = self._tail_workspace(b, hs, w, "global")
         self.ops.gabor_features(strip, ws["feats"])
         k, dfeat = self.k, self.bank.n_features

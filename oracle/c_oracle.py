@@ -13,20 +13,19 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])       # no-op when up to date
         _lib = C.CDLL(_SO)
     return _lib
 
 
-def gabor_features(img, tapq, shift):
+def gabor_features(img, tapq, shift, n_orient):
     img = np.ascontiguousarray(img, np.uint8)
     tapq = np.ascontiguousarray(tapq, np.int16)
     h, w = img.shape[:2]
     f, _, ks, _ = tapq.shape
     out = np.empty((3 * f, h, w), np.uint16)
     rc = load().oracle_gabor_features(C.c_void_p(img.ctypes.data), h, w, C.c_void_p(tapq.ctypes.data), f, ks,
-                                      int(shift), C.c_void_p(out.ctypes.data))
+                                      int(shift), int(n_orient), C.c_void_p(out.ctypes.data))
     assert rc == 0
     return out
 
@@ -43,10 +42,10 @@ def kmeans(feats, k, n_iter):
     return labels, cent
 
 
-def segment_batch(imgs, tapq, shift, k=8, n_iter=10, mode="per_image"):
+def segment_batch(imgs, tapq, shift, n_orient, k=8, n_iter=10, mode="per_image"):
     imgs = np.asarray(imgs)
     b, h, w = imgs.shape[:3]
-    feats = np.stack([gabor_features(im, tapq, shift) for im in imgs]).reshape(b, -1, h * w)
+    feats = np.stack([gabor_features(im, tapq, shift, n_orient) for im in imgs]).reshape(b, -1, h * w)
     if mode == "global":
         return kmeans(feats, k, n_iter)[0].reshape(b, h, w)
     return np.stack([kmeans(feats[i:i + 1], k, n_iter)[0].reshape(h, w) for i in range(b)])

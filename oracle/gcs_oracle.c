@@ -1,6 +1,6 @@
 /* CPU ORACLE IN C — TEST INFRASTRUCTURE ONLY. Never linked into or called by the product.
  *
- * A second, independent restatement of SPEC.md §3-§4 (explicit reflect indexing and plain
+ * A second, independent restatement of SPEC.md §3-§4 (explicit pyramid / reflect indexing and plain
  * loops; oracle/spec_oracle.py uses scipy.ndimage instead). PARITY UNPINNED against the
  * reference: /root/reference holds no Gabor or k-means code to restate (the
  * slot is /root/reference/BSD_metrics/script.py:30). Pinned only against spec_oracle.py
@@ -30,39 +30,80 @@ static uint32_t isqrt64(uint64_t n) {
     return (uint32_t)lo;
 }
 
-/* SPEC.md §3: img [H][W][3] u8, tapq [F][2][ks][ks] i16 -> out [3F][H][W] u16, d = c*F + f */
+/* SPEC.md §3 pyramid step: src [Hs][Ws][3] u8 -> dst [ceil(Hs/2)][ceil(Ws/2)][3] u8, the 2x2 block mean
+ * (round half up) of src edge-replicated to even size. */
+static void pyramid_down(const uint8_t *src, int Hs, int Ws, uint8_t *dst) {
+    const int Hd = (Hs + 1) / 2, Wd = (Ws + 1) / 2;
+    for (int y = 0; y < Hd; ++y)
+        for (int x = 0; x < Wd; ++x)
+            for (int c = 0; c < 3; ++c) {
+                int acc = 2;
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        const int yy = 2 * y + i < Hs ? 2 * y + i : Hs - 1;
+                        const int xx = 2 * x + j < Ws ? 2 * x + j : Ws - 1;
+                        acc += src[((size_t)yy * Ws + xx) * 3 + c];
+                    }
+                dst[((size_t)y * Wd + x) * 3 + c] = (uint8_t)(acc >> 2);
+            }
+}
+
+/* One filter on one level image: lev [Hl][Wl][3] u8, channel c -> g [Hl][Wl] u16 (SPEC.md §3 response). */
+static void level_response(const uint8_t *lev, int Hl, int Wl, int c, const int16_t *tre, const int16_t *tim, int ks,
+                           int shift, const int *ry, const int *rx, uint16_t *g) {
+    for (int y = 0; y < Hl; ++y)
+        for (int x = 0; x < Wl; ++x) {
+            int64_t vre = 0, vim = 0;
+            for (int dy = 0; dy < ks; ++dy) {
+                const uint8_t *row = lev + (size_t)ry[y + dy] * Wl * 3 + c;
+                for (int dx = 0; dx < ks; ++dx) {
+                    const int64_t p = row[(size_t)rx[x + dx] * 3];
+                    vre += p * tre[dy * ks + dx];
+                    vim += p * tim[dy * ks + dx];
+                }
+            }
+            /* arithmetic shift == floor division by 2^shift */
+            const int64_t are = vre >= 0 ? vre >> shift : -((-vre + ((int64_t)1 << shift) - 1) >> shift);
+            const int64_t aim = vim >= 0 ? vim >> shift : -((-vim + ((int64_t)1 << shift) - 1) >> shift);
+            g[(size_t)y * Wl + x] = (uint16_t)isqrt64((uint64_t)(are * are + aim * aim));
+        }
+}
+
+/* SPEC.md §3: img [H][W][3] u8, tapq [F][2][ks][ks] i16 -> out [3F][H][W] u16, d = c*F + f. Filter f runs on
+ * pyramid level (f / n_orient) / 2 and its response is replicated over 2^L x 2^L blocks. */
 int oracle_gabor_features(const uint8_t *img, int H, int W, const int16_t *tapq, int F, int ks, int shift,
-                          uint16_t *out) {
+                          int n_orient, uint16_t *out) {
     const int R = (ks - 1) / 2;
+    const int n_levels = ((F - 1) / n_orient) / 2 + 1;
+    uint8_t *lev = (uint8_t *)malloc((size_t)H * W * 3), *nxt = (uint8_t *)malloc((size_t)H * W * 3);
+    uint16_t *g = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)H * W);
     int *ry = (int *)malloc(sizeof(int) * (size_t)(H + 2 * R));
     int *rx = (int *)malloc(sizeof(int) * (size_t)(W + 2 * R));
-    if (!ry || !rx) return 1;
-    for (int i = 0; i < H + 2 * R; ++i) ry[i] = refl(i - R, H);
-    for (int i = 0; i < W + 2 * R; ++i) rx[i] = refl(i - R, W);
-    for (int c = 0; c < 3; ++c)
+    if (!lev || !nxt || !g || !ry || !rx) return 1;
+    memcpy(lev, img, (size_t)H * W * 3);
+    int Hl = H, Wl = W;
+    for (int L = 0; L < n_levels; ++L) {
+        for (int i = 0; i < Hl + 2 * R; ++i) ry[i] = refl(i - R, Hl);
+        for (int i = 0; i < Wl + 2 * R; ++i) rx[i] = refl(i - R, Wl);
         for (int f = 0; f < F; ++f) {
+            if ((f / n_orient) / 2 != L) continue;
             const int16_t *tre = tapq + ((size_t)f * 2 + 0) * ks * ks;
             const int16_t *tim = tapq + ((size_t)f * 2 + 1) * ks * ks;
-            uint16_t *o = out + ((size_t)c * F + f) * H * W;
-            for (int y = 0; y < H; ++y)
-                for (int x = 0; x < W; ++x) {
-                    int64_t vre = 0, vim = 0;
-                    for (int dy = 0; dy < ks; ++dy) {
-                        const uint8_t *row = img + (size_t)ry[y + dy] * W * 3 + c;
-                        for (int dx = 0; dx < ks; ++dx) {
-                            const int64_t p = row[(size_t)rx[x + dx] * 3];
-                            vre += p * tre[dy * ks + dx];
-                            vim += p * tim[dy * ks + dx];
-                        }
-                    }
-                    /* arithmetic shift == floor division by 2^shift */
-                    const int64_t are = vre >= 0 ? vre >> shift : -((-vre + ((int64_t)1 << shift) - 1) >> shift);
-                    const int64_t aim = vim >= 0 ? vim >> shift : -((-vim + ((int64_t)1 << shift) - 1) >> shift);
-                    o[(size_t)y * W + x] = (uint16_t)isqrt64((uint64_t)(are * are + aim * aim));
-                }
+            for (int c = 0; c < 3; ++c) {
+                level_response(lev, Hl, Wl, c, tre, tim, ks, shift, ry, rx, g);
+                uint16_t *o = out + ((size_t)c * F + f) * H * W;
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) o[(size_t)y * W + x] = g[(size_t)(y >> L) * Wl + (x >> L)];
+            }
         }
-    free(ry);
-    free(rx);
+        if (L + 1 < n_levels) {
+            pyramid_down(lev, Hl, Wl, nxt);
+            uint8_t *t = lev; lev = nxt; nxt = t;
+            Hl = (Hl + 1) / 2;
+            Wl = (Wl + 1) / 2;
+        }
+    }
+    free(lev); free(nxt); free(g); free(ry); free(rx);
     return 0;
 }
 

@@ -37,7 +37,7 @@ def bank(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0), band
     kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * (2.0 ** bandwidth + 1.0) / (2.0 ** bandwidth - 1.0)
     taps = []
     for s in range(n_scales):
-        freq = f_max / ratio ** s
+        freq = f_max / ratio ** s * 2.0 ** (s // 2)      # f_base on pyramid level s // 2
         sigma = kappa / freq
         env = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma))
         env = env / env.sum()
@@ -60,20 +60,53 @@ def isqrt_array(n: np.ndarray) -> np.ndarray:
     return q
 
 
-def gabor_features(img: np.ndarray, tapq: np.ndarray, shift: int) -> np.ndarray:
-    """SPEC.md §3. img (H,W,3) uint8 -> feats (3F,H,W) uint16, d = c*F + f."""
+def pyramid(img: np.ndarray, n_levels: int):
+    """SPEC.md §3 pyramid: I_0 = img, I_{L+1} = 2x2 block mean (round half up) of I_L edge-replicated to even size."""
+    levels = [np.asarray(img)]
+    for _ in range(1, n_levels):
+        a = levels[-1].astype(np.int64)
+        a = np.pad(a, ((0, a.shape[0] & 1), (0, a.shape[1] & 1), (0, 0)), mode="edge")
+        levels.append(((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    return levels
+
+
+def level_of(f: int, n_orient: int) -> int:
+    return (f // n_orient) // 2
+
+
+def gabor_features_levels(img: np.ndarray, tapq: np.ndarray, shift: int, n_orient: int):
+    """SPEC.md §3 responses at their own resolution: list over levels of (3F, H_L, W_L) uint16 arrays in which
+    only the rows d = c*F + f of that level's filters are filled (the others stay zero)."""
     assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    nf = tapq.shape[0]
+    n_levels = level_of(nf - 1, n_orient) + 1
+    out = []
+    for lv, im in enumerate(pyramid(img, n_levels)):
+        g = np.zeros((3 * nf,) + im.shape[:2], np.uint16)
+        for c in range(3):
+            chan = im[:, :, c].astype(np.int64)
+            for f in range(nf):
+                if level_of(f, n_orient) != lv:
+                    continue
+                v_re = ndi.correlate(chan, tapq[f, 0], mode='reflect')
+                v_im = ndi.correlate(chan, tapq[f, 1], mode='reflect')
+                a_re = v_re >> shift
+                a_im = v_im >> shift
+                g[c * nf + f] = isqrt_array(a_re * a_re + a_im * a_im)
+        out.append(g)
+    return out
+
+
+def gabor_features(img: np.ndarray, tapq: np.ndarray, shift: int, n_orient: int) -> np.ndarray:
+    """SPEC.md §3. img (H,W,3) uint8 -> canonical feats (3F,H,W) uint16, d = c*F + f: level-L responses
+    replicated over their 2^L x 2^L blocks."""
     nf = tapq.shape[0]
     h, w = img.shape[:2]
     out = np.empty((3 * nf, h, w), np.uint16)
-    for c in range(3):
-        chan = img[:, :, c].astype(np.int64)
-        for f in range(nf):
-            v_re = ndi.correlate(chan, tapq[f, 0], mode='reflect')
-            v_im = ndi.correlate(chan, tapq[f, 1], mode='reflect')
-            a_re = v_re >> shift
-            a_im = v_im >> shift
-            out[c * nf + f] = isqrt_array(a_re * a_re + a_im * a_im)
+    for lv, g in enumerate(gabor_features_levels(img, tapq, shift, n_orient)):
+        rows = [c * nf + f for c in range(3) for f in range(nf) if level_of(f, n_orient) == lv]
+        up = g[rows].repeat(1 << lv, axis=1).repeat(1 << lv, axis=2)
+        out[rows] = up[:, :h, :w]
     return out
 
 
@@ -132,7 +165,7 @@ def segment(img, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=15, f_max=0.4,
             ratio=math.sqrt(2.0), bandwidth=1.0, return_all=False):
     """segment(image) -> (H,W) int32 label map (per-image codebook)."""
     tapq, shift = bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
-    feats = gabor_features(img, tapq, shift)
+    feats = gabor_features(img, tapq, shift, n_orient)
     h, w = img.shape[:2]
     x = feats.reshape(feats.shape[0], -1).T
     lab, c = kmeans(x, k, n_iter)
@@ -149,7 +182,8 @@ def segment_batch(imgs, mode="per_image", **kw):
         return np.stack([segment(im, k=k, n_iter=n_iter, **bank_kw) for im in imgs])
     tapq, shift = bank(**bank_kw)
     b, h, w = imgs.shape[:3]
-    xs = [gabor_features(im, tapq, shift).reshape(3 * tapq.shape[0], -1).T for im in imgs]
+    n_orient = bank_kw.get("n_orient", 6)
+    xs = [gabor_features(im, tapq, shift, n_orient).reshape(3 * tapq.shape[0], -1).T for im in imgs]
     x = np.concatenate(xs)
     lab, _ = kmeans(x, k, n_iter, init_from=xs[0])
     return lab.reshape(b, h, w).astype(np.int32)

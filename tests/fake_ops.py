@@ -33,7 +33,7 @@ class OracleOps:
     def gabor_features(self, imgs, feats):
         self.calls.append(("gabor", imgs.shape[0]))
         arr = imgs.numpy()
-        feats["x"] = np.stack([so.gabor_features(im, self.tapq, self.bank.shift).reshape(self.bank.n_features, -1).T
+        feats["x"] = np.stack([so.gabor_features(im, self.tapq, self.bank.shift, self.bank.n_orient).reshape(self.bank.n_features, -1).T
                                for im in arr]).astype(np.int64)      # (B, P, D)
 
     def kmeans_init(self, feats, b, h, w, k, n_sets, cent):

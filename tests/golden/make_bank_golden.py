@@ -3,7 +3,7 @@
 The reference tree has no Gabor code, but it is a scikit-image program (script.py:9-11 import
 skimage) and scikit-image publishes a Gabor kernel. This script stores
 ``skimage.filters.gabor_kernel(frequency, theta, bandwidth)`` for every (scale, orientation) of the
-default bank and of one 8x8 bank, so that SPEC.md §2's envelope, bandwidth -> sigma rule, rotation
+default bank and of one 8x8 bank (at the base frequency f_s * 2^(s//2) of the filter's pyramid level), so that SPEC.md §2's envelope, bandwidth -> sigma rule, rotation
 convention and phase are pinned to a published definition (tests/test_bank.py). Kernels are stored
 on a fixed 31x31 frame centred on the origin (zero outside skimage's own support).
 """
@@ -21,7 +21,7 @@ out = {}
 for name, (ns, no) in {"b4x6": (4, 6), "b8x8": (8, 8)}.items():
     frames = np.zeros((ns * no, 2 * R + 1, 2 * R + 1), np.complex128)
     for s in range(ns):
-        freq = 0.4 / math.sqrt(2.0) ** s
+        freq = 0.4 / math.sqrt(2.0) ** s * 2.0 ** (s // 2)       # f_base on pyramid level s // 2 (SPEC.md §2)
         for o in range(no):
             g = gabor_kernel(freq, theta=o * math.pi / no, bandwidth=1.0)
             ry, rx = g.shape[0] // 2, g.shape[1] // 2

@@ -39,11 +39,12 @@ def test_float_taps_are_the_scikit_image_gabor_kernel(name, ns, no):
     kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * 3.0
     dy, dx = np.mgrid[-7:8, -7:8]
     for f in range(ns * no):
-        sigma = kappa / (0.4 / math.sqrt(2.0) ** (f // no))
+        s_ = f // no
+        sigma = kappa / (0.4 / math.sqrt(2.0) ** s_ * 2.0 ** (s_ // 2))        # f_base of pyramid level s // 2
         gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
         mine = (taps[f, 0] + 1j * taps[f, 1]) * gain
         support = np.abs(ref[f]) > 0                               # skimage truncates at 3 sigma
-        assert support.sum() >= 49
+        assert support.sum() >= 49 and not support[[0, -1]].any() and not support[:, [0, -1]].any()   # inside the 15x15 frame
         assert np.abs(mine - ref[f])[support].max() < 1e-15
         # the quantised bank the kernels run is that kernel to within half an LSB
         b = make_bank(n_scales=ns, n_orient=no)
@@ -62,6 +63,19 @@ def test_symmetry_and_zero_dc_of_imaginary_part():
     assert np.abs(im).sum(axis=(1, 2)).max() <= 2 ** b.exponent
 
 
+@pytest.mark.parametrize("ns,no", [(4, 6), (8, 8), (3, 5), (1, 1)])
+def test_every_filter_is_band_pass(ns, no):
+    """SPEC.md §2: every filter keeps >= 3 sigma of its envelope inside the 15x15 frame, so the real part's DC gain is
+    exp(-2 pi^2 kappa^2) = 0.002 (round 1's full-resolution coarse scales reached 0.61)."""
+    b = make_bank(ns, no)
+    assert b.n_levels == (ns + 1) // 2
+    dc = np.abs(b.tapq[:, 0].astype(np.int64).sum(axis=(1, 2))) / 2.0 ** b.exponent
+    assert dc.max() < 0.01
+    # and the two base scales repeat from level to level (ratio = sqrt 2): one set of kernels serves every level
+    for f in range(2 * no, ns * no):
+        assert np.array_equal(b.tapq[f], b.tapq[f - 2 * no])
+
+
 def test_digits_recombine():
     b = make_bank()
     lo, hi = split_digits(b.tapq)
@@ -76,7 +90,7 @@ def test_other_banks_match_oracle(ns, no, ks):
     assert np.array_equal(tq, b.tapq) and sh == b.shift
 
 
-@pytest.mark.parametrize("kw", [dict(ksize=16), dict(ksize=17), dict(ksize=0), dict(n_scales=0), dict(n_orient=0)])
+@pytest.mark.parametrize("kw", [dict(ksize=16), dict(ksize=17), dict(ksize=0), dict(n_scales=0), dict(n_orient=0), dict(n_scales=9)])
 def test_bad_parameters_raise(kw):
     with pytest.raises(ValueError):
         make_bank(**kw)

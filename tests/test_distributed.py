@@ -84,7 +84,7 @@ def test_row_sharded_image_on_gpu_two_ranks(tmp_path, built):
     mp.spawn(_strip_worker, args=(2, port, b, height, width, 5, 8, str(tmp_path), True), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)], axis=1)
     tapq, shift = so.bank()
-    ref = co.segment_batch(synthetic_batch(b, height, width, seed=13), tapq, shift, k=8, n_iter=5, mode="global")
+    ref = co.segment_batch(synthetic_batch(b, height, width, seed=13), tapq, shift, 6, k=8, n_iter=5, mode="global")
     assert np.array_equal(got, ref)
 
 

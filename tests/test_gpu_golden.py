@@ -67,7 +67,7 @@ def test_full_size_batch_vs_c_oracle_and_properties(seg):
     imgs = synthetic_batch(6, 321, 481, seed=0)
     out = seg.segment_batch(imgs)
     assert out.shape == (6, 321, 481) and out.min() >= 0 and out.max() <= 7
-    ref = co.segment_batch(imgs[[0, 5]], seg.bank.tapq, seg.bank.shift)
+    ref = co.segment_batch(imgs[[0, 5]], seg.bank.tapq, seg.bank.shift, 6)
     assert np.array_equal(out[0], ref[0]) and np.array_equal(out[5], ref[1])
     assert np.array_equal(seg(imgs[3]), out[3])                      # segment == segment_batch row
     assert np.array_equal(seg.segment_batch(imgs), out)              # deterministic
@@ -78,7 +78,7 @@ def test_global_codebook_full_size_vs_c_oracle(seg):
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     imgs = synthetic_batch(3, 321, 481, seed=9)
     got = seg.segment_batch(imgs, mode="global")
-    assert np.array_equal(got, co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, mode="global"))
+    assert np.array_equal(got, co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, 6, mode="global"))
 
 
 def test_k16_two_mfma_tiles_and_portrait(built):
@@ -87,7 +87,7 @@ def test_k16_two_mfma_tiles_and_portrait(built):
     imgs = synthetic_batch(2, 481, 321, seed=4)
     s = Segmenter(k=16, n_iter=4)
     got = s.segment_batch(imgs)
-    ref = co.segment_batch(imgs, s.bank.tapq, s.bank.shift, k=16, n_iter=4)
+    ref = co.segment_batch(imgs, s.bank.tapq, s.bank.shift, 6, k=16, n_iter=4)
     assert np.array_equal(got, ref)
 
 
@@ -112,7 +112,7 @@ def test_sixty_four_filter_bank_features(built):
     s = Segmenter(n_scales=8, n_orient=8)
     got = s.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)[0]
     tapq, shift = so.bank(8, 8)
-    assert np.array_equal(got, co.gabor_features(imgs[0], tapq, shift))
+    assert np.array_equal(got, co.gabor_features(imgs[0], tapq, shift, 8))
 
 
 def test_degenerate_inputs(seg):
@@ -150,4 +150,4 @@ def test_sixty_four_filter_bank_full_segment(built):
     s = Segmenter(n_scales=8, n_orient=8, k=6, n_iter=3)
     got = s.segment_batch(imgs, mode="global")
     tapq, shift = so.bank(8, 8)
-    assert np.array_equal(got, co.segment_batch(imgs, tapq, shift, k=6, n_iter=3, mode="global"))
+    assert np.array_equal(got, co.segment_batch(imgs, tapq, shift, 8, k=6, n_iter=3, mode="global"))

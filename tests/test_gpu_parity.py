@@ -28,7 +28,7 @@ def test_features_bit_exact_default_bank(torch_cuda, h, w):
     got = seg.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)
     tapq, shift = so.bank()
     for b in range(2):
-        ref = so.gabor_features(imgs[b], tapq, shift)
+        ref = so.gabor_features(imgs[b], tapq, shift, 6)
         assert got[b].shape == ref.shape
         bad = np.argwhere(got[b] != ref)
         assert bad.size == 0, f"{len(bad)} mismatches, first {bad[:5]}, got {got[b][tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
@@ -42,7 +42,7 @@ def test_features_bit_exact_other_banks(torch_cuda, ns, no, ks):
     seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks)
     got = seg.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)
     tapq, shift = so.bank(ns, no, ks)
-    ref = so.gabor_features(imgs[0], tapq, shift)
+    ref = so.gabor_features(imgs[0], tapq, shift, no)
     assert np.array_equal(got[0], ref)
 
 
@@ -58,7 +58,7 @@ def test_features_extreme_pixels(torch_cuda):
     got = seg.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)
     tapq, shift = so.bank()
     for b in range(3):
-        assert np.array_equal(got[b], so.gabor_features(imgs[b], tapq, shift))
+        assert np.array_equal(got[b], so.gabor_features(imgs[b], tapq, shift, 6))
 
 
 @pytest.mark.parametrize("k,n_iter", [(8, 10), (3, 4), (16, 3), (1, 2), (5, 1)])
@@ -133,7 +133,7 @@ def test_randomised_shapes_banks_and_codebooks(torch_cuda):
             imgs = rng.integers(0, 256, imgs.shape, dtype=np.uint8)
         seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=n_iter, connectivity=conn)
         got = seg.segment_batch(imgs, mode=mode)
-        ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, k=k, n_iter=n_iter, mode=mode)
+        ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, no, k=k, n_iter=n_iter, mode=mode)
         if conn:
             ref = np.stack([so.connected_regions(r) for r in ref])
         assert np.array_equal(got, ref), dict(case=case, h=h, w=w, b=b, bank=(ns, no, ks), k=k, n_iter=n_iter,

@@ -20,7 +20,7 @@ def test_delta_image_returns_the_kernel_magnitude():
     tapq, shift = so.bank()
     img = np.zeros((41, 41, 3), np.uint8)
     img[20, 20, 1] = 200
-    feats = so.gabor_features(img, tapq, shift)
+    feats = so.gabor_features(img, tapq, shift, 6)
     f = 7
     re = (tapq[f, 0] * 200) >> shift
     im = (tapq[f, 1] * 200) >> shift
@@ -32,7 +32,7 @@ def test_delta_image_returns_the_kernel_magnitude():
 def test_constant_image_gives_the_dc_gain():
     tapq, shift = so.bank()
     img = np.full((20, 24, 3), 173, np.uint8)
-    feats = so.gabor_features(img, tapq, shift)
+    feats = so.gabor_features(img, tapq, shift, 6)
     for f in range(24):
         a = (int(tapq[f, 0].sum()) * 173) >> shift
         assert np.all(feats[f] == abs(a))          # imaginary part sums to zero exactly
@@ -67,8 +67,9 @@ def test_c_oracle_equals_numpy_oracle(shape, bank_kw):
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
     tapq, shift = so.bank(**bank_kw)
-    a = so.gabor_features(img, tapq, shift)
-    b = co.gabor_features(img, tapq, shift)
+    no = bank_kw.get("n_orient", 6)
+    a = so.gabor_features(img, tapq, shift, no)
+    b = co.gabor_features(img, tapq, shift, no)
     assert np.array_equal(a, b)
     x = a.reshape(a.shape[0], -1)
     for k, n_iter in [(8, 5), (3, 2), (16, 3)]:
@@ -82,7 +83,7 @@ def test_c_oracle_global_mode_equals_numpy():
     imgs = synthetic_batch(3, 24, 40, seed=4)
     tapq, shift = so.bank()
     a = so.segment_batch(imgs, mode="global", n_iter=4)
-    b = co.segment_batch(imgs, tapq, shift, n_iter=4, mode="global")
+    b = co.segment_batch(imgs, tapq, shift, 6, n_iter=4, mode="global")
     assert np.array_equal(a, b)
 
 
@@ -95,7 +96,7 @@ def test_oracle_reproduces_committed_path_golden():
     for i in inp["ids"][:2]:                              # one landscape, one portrait
         img = inp["img_" + str(i)]
         h, w = img.shape[:2]
-        feats = co.gabor_features(img, tapq, shift)
+        feats = co.gabor_features(img, tapq, shift, 6)
         flat = feats.reshape(72, -1)
         assert np.array_equal(flat.astype(np.int64).sum(axis=1), g["feat_sum_" + str(i)])
         assert np.array_equal(flat.max(axis=1), g["feat_max_" + str(i)])
@@ -137,7 +138,7 @@ def test_integer_kmeans_tracks_scikit_learn_lloyd():
     g = np.load(os.path.join(GOLD, "path_golden.npz"))
     i = str(inp["ids"][0])
     tapq, shift = so.bank()
-    x = so.gabor_features(inp["img_" + i], tapq, shift).reshape(72, -1).T.astype(np.float64)
+    x = so.gabor_features(inp["img_" + i], tapq, shift, 6).reshape(72, -1).T.astype(np.float64)
     km = KMeans(n_clusters=8, init=so.kmeans_init(x, 8).astype(np.float64), n_init=1, max_iter=9,
                 tol=0.0, algorithm="lloyd").fit(x)
     assert km.n_iter_ == 9
@@ -145,22 +146,74 @@ def test_integer_kmeans_tracks_scikit_learn_lloyd():
     assert np.abs(km.cluster_centers_ - g["centroids_" + i]).max() < 4.0
 
 
-def test_features_are_the_scikit_image_gabor_filter_magnitude():
-    """The feature stage against a published implementation: skimage.filters.gabor (convolution with its own
-    gabor_kernel, mode='reflect') on a crop of a BSD fixture, red channel, the 12 filters of the two finest scales
-    (fixture from tests/golden/make_feature_golden.py). SPEC.md's features are that magnitude divided by the
-    unit-DC gain, up to the 15x15 truncation (skimage cuts at 3 sigma) and the Q7 fixed-point rounding: within
-    0.05 grey level at the finest scale, 0.2 at the next (magnitudes reach 14.6)."""
+@pytest.mark.parametrize("name,ns,no", [("b4x6", 4, 6), ("b8x8", 8, 8)])
+def test_every_filter_is_the_scikit_image_gabor_filter_on_its_pyramid_level(name, ns, no):
+    """SPEC.md §3 against published code, filter by filter (fixture: tests/golden/make_feature_golden.py, run under the
+    interpreter that has scikit-image): ALL 24 filters of the default bank and all 64 of the 8x8 bank.
+
+    * the pyramid levels equal floor(skimage.transform.downscale_local_mean(level, (2,2)) + 0.5) of the edge-padded
+      level, exactly;
+    * the oracle's Q7 response of filter (s, o) on level L = s // 2 equals the magnitude of skimage.filters.gabor (its
+      own gabor_kernel, mode='reflect') run on that level at f_base = f_s * 2^L, divided by the unit-DC gain. The
+      residue is skimage's support box, ceil(3 sigma max(|cos|, |sin|)) pixels, against SPEC.md's fixed 15x15 frame,
+      plus the Q7 rounding: within 0.07 grey level where skimage keeps >= 3.5 sigma, 0.2 where it keeps >= 2.8 sigma,
+      0.4 on the diagonals of the 8-orientation bank, which skimage cuts at 2.1 sigma (magnitudes reach 20)."""
     import math
     z = np.load(os.path.join(GOLD, "features_skimage.npz"))
-    tapq, shift = so.bank()
-    feats = so.gabor_features(z["crop"], tapq, shift)[:12].astype(np.float64) / 128.0     # channel 0, Q7 -> grey levels
+    crop, stride0 = z[name + "_crop"], int(z[name + "_stride0"])
+    tapq, shift = so.bank(ns, no)
+    levels = so.pyramid(crop, (ns + 1) // 2)
+    mine = so.gabor_features_levels(crop, tapq, shift, no)
     kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * 3.0
     dy, dx = np.mgrid[-7:8, -7:8]
-    for f in range(12):
-        sigma = kappa / (0.4 / math.sqrt(2.0) ** (f // 6))
-        gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
-        ref = z["magnitude"][f].astype(np.float64) / gain
-        assert ref.max() > 5.0
-        assert np.abs(feats[f] - ref).max() < (0.05 if f < 6 else 0.2), f
-    assert np.array_equal(feats * 128.0, co.gabor_features(z["crop"], tapq, shift)[:12])   # and the C oracle agrees
+    checked = 0
+    for lv in range((ns + 1) // 2):
+        assert np.array_equal(levels[lv][:, :, 0], z[f"{name}_level{lv}"])
+        st = stride0 if lv == 0 else 1
+        ref = z[f"{name}_mag{lv}"].astype(np.float64)
+        for i, s in enumerate(range(2 * lv, min(ns, 2 * lv + 2))):
+            sigma = kappa / (0.4 / math.sqrt(2.0) ** s * 2.0 ** lv)
+            gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
+            for o in range(no):
+                th = o * math.pi / no
+                kept = math.ceil(max(abs(3 * sigma * math.cos(th)), abs(3 * sigma * math.sin(th)), 1)) / sigma
+                tol = 0.07 if kept >= 3.5 else 0.2 if kept >= 2.8 else 0.4
+                got = mine[lv][s * no + o][::st, ::st].astype(np.float64) / 128.0      # channel 0, Q7 -> grey levels
+                want = ref[i * no + o] / gain
+                assert want.max() > 4.0
+                assert np.abs(got - want).max() < tol, (s, o, kept)
+                checked += 1
+    assert checked == ns * no
+    # the canonical (upsampled) tensor is those responses replicated over 2^L blocks, and the C oracle agrees
+    full = so.gabor_features(crop, tapq, shift, no)
+    for f in (0, ns * no - 1):
+        lv = so.level_of(f, no)
+        assert np.array_equal(full[f][5::7, 3::5], mine[lv][f][(np.arange(5, crop.shape[0], 7) >> lv)][:, np.arange(3, crop.shape[1], 5) >> lv])
+    assert np.array_equal(full, co.gabor_features(crop, tapq, shift, no))
+
+
+def test_pyramid_hand_cases():
+    """2x2 block mean, round half up, edge replication for odd sizes (SPEC.md §3)."""
+    img = np.zeros((3, 5, 3), np.uint8)
+    img[..., 0] = [[1, 2, 3, 4, 9], [1, 2, 3, 5, 10], [7, 7, 7, 8, 255]]
+    l0, l1, l2 = so.pyramid(img, 3)
+    assert l1.shape == (2, 3, 3) and l2.shape == (1, 2, 3)
+    assert l1[..., 0].tolist() == [[2, 4, 10], [7, 8, 255]]       # (1+2+1+2+2)>>2 = 2, (3+4+3+5+2)>>2 = 4, (9+9+10+10+2)>>2 = 10
+    assert l2[..., 0].tolist() == [[5, 133]]                       # (2+4+7+8+2)>>2 = 5, (10+10+255+255+2)>>2 = 133
+    assert np.all(l1[..., 1:] == 0)
+
+
+def test_delta_image_on_a_coarse_level():
+    """A 2x2 bright block on black is a single level-1 pixel: level-1 filters return their kernel magnitude,
+    replicated over 2x2 blocks; filter 13 = scale 2, orientation 1 lives on level 1."""
+    tapq, shift = so.bank()
+    img = np.zeros((64, 64, 3), np.uint8)
+    img[30:32, 40:42, 2] = 200
+    feats = so.gabor_features(img, tapq, shift, 6)
+    f = 13
+    re = (tapq[f, 0] * 200) >> shift
+    im = (tapq[f, 1] * 200) >> shift
+    expect = so.isqrt_array(re * re + im * im)[::-1, ::-1]
+    got = feats[48 + f]
+    assert np.array_equal(got[16:46:2, 26:56:2], expect)
+    assert np.array_equal(got[16:46:2, 26:56:2], got[17:47:2, 27:57:2])
