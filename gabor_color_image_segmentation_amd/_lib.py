@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -21,25 +21,25 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SIGNATURES = {
     "gcs_abi_version": (_i, []),
     "gcs_last_error": (C.c_char_p, []),
-    "gcs_bank_packed_bytes": (_sz, [_i]),
-    "gcs_bank_bias_count": (_sz, [_i]),
-    "gcs_bank_pack": (_i, [_vp, _i, _i, _vp, _vp]),
-    "gcs_feature_pitch": (_sz, [_i]),
-    "gcs_feature_plane_stride": (_sz, [_i, _i]),
-    "gcs_feature_slab_bytes": (_sz, [_i, _i, _i, _i]),
+    "gcs_bank_packed_bytes": (_sz, [_i, _i]),
+    "gcs_bank_bias_count": (_sz, [_i, _i]),
+    "gcs_bank_pack": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "gcs_feature_slab_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gcs_label_slab_bytes": (_sz, [_i, _i, _i]),
     "gcs_kmeans_parts_per_image": (_sz, [_i, _i, _i]),
     "gcs_kmeans_partial_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "gcs_gabor_workspace_bytes": (_sz, [_i, _i, _i]),
-    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "gcs_features_unpack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "gcs_features_gather": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_gabor_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_features_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gcs_features_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_kmeans_reduce": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_finalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_reduce_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_labels_widen": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "gcs_labels_raster_u8": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "gcs_selftest_isqrt": (_i, [C.c_uint, _vp, _vp]),
     "gcs_boundary_scratch_bytes": (_sz, [_i, _i, _i]),
     "gcs_boundary_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_region_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

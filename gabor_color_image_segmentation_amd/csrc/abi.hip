@@ -1,0 +1,130 @@
+// abi.hip — host-only part of the C ABI (include/gcs.h): error plumbing, slab geometry, bank packing.
+// The reference ships no code for this path; the slot filled is
+// /root/reference/BSD_metrics/script.py:30. Arithmetic: SPEC.md.
+#include "common.h"
+
+static thread_local char g_err[256] = "";
+int gcs_fail(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+int gcs_hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return GCS_EHIP;
+}
+
+extern "C" int gcs_abi_version(void) { return GCS_ABI_VERSION; }
+extern "C" const char *gcs_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------- geometry (host)
+static bool bank_levels(int n_scales, int n_orient, int FL[GCS_LEVELS_MAX], int *n_levels) {
+    if (n_scales < 1 || n_scales > GCS_SCALES_MAX || n_orient < 1 || n_orient > 2730) return false;
+    *n_levels = (n_scales + 1) / 2;
+    for (int L = 0; L < *n_levels; ++L) FL[L] = (n_scales - 2 * L >= 2 ? 2 : 1) * n_orient;
+    return true;
+}
+
+extern "C" size_t gcs_bank_packed_bytes(int n_scales, int n_orient) {
+    int FL[GCS_LEVELS_MAX], nl;
+    if (!bank_levels(n_scales, n_orient, FL, &nl)) return 0;
+    size_t mt = 0;
+    for (int L = 0; L < nl; ++L) mt += mtiles(FL[L]);
+    return mt * 8 * 64 * 16;
+}
+extern "C" size_t gcs_bank_bias_count(int n_scales, int n_orient) {
+    int FL[GCS_LEVELS_MAX], nl;
+    if (!bank_levels(n_scales, n_orient, FL, &nl)) return 0;
+    size_t mt = 0;
+    for (int L = 0; L < nl; ++L) mt += mtiles(FL[L]);
+    return mt * 8;
+}
+extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient) {
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo)) return 0;
+    return (size_t)B * lo.ntiles * lo.tile_bytes;
+}
+extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
+    return (size_t)B * lo.ntiles * KP_TP;
+}
+// Workgroups (= partial-sum rows) per image of one Lloyd pass. Sized to the machine: the pass
+// kernel runs 3 workgroups per CU, so B*parts aims at one full wave of 256*3 workgroups (a
+// second, partly filled wave of workgroups would idle most of the chip). Lower bound: one
+// workgroup's int32 accumulators must not overflow (<= 65536 pixels); upper bound: at least
+// 8 tiles per workgroup to amortise its prologue.
+#ifndef GCS_KP_SLOTS
+#define GCS_KP_SLOTS 768
+#endif
+extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
+    const size_t px = (size_t)lo.ntiles * KP_TP;
+    const size_t need = (px + 65535) / 65536;
+    size_t most = px / KP_TP / 8;
+    if (most < 1) most = 1;
+    size_t want = (GCS_KP_SLOTS + (size_t)B - 1) / (size_t)B;
+    if (want > most) want = most;
+    return need > want ? need : want;
+}
+extern "C" size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k) {
+    if (B <= 0 || D <= 0 || k <= 0) return 0;
+    return (size_t)B * gcs_kmeans_parts_per_image(B, H, W) * k * (D + 1) * sizeof(uint64_t);
+}
+
+// ------------------------------------------------------------------------ bank pack (host)
+// A-fragment of v_mfma_i32_32x32x32_i8: lane l = (r = l&31, h = l>>5) supplies row r of the
+// 32-row tile, 16 consecutive k. We bind k-slot (kk, h, j) to tap (dy = 2*kk + h, dx = j) of
+// a 16x16 frame whose row 15 / column 15 are zero; both operands use the same binding, so
+// only "A row = lane&31, B col = lane&31" and the C/D map (cdna guide §3) are relied on.
+// Row r of tile mt = filter 8*mt + r/4 OF ITS LEVEL, part r%4 in {re_lo, re_hi, im_lo, im_hi}: the four
+// parts of one filter land in one lane's accumulator quad (rows 4g..4g+3). Levels are packed one after
+// the other, each starting on a fresh tile: [level][mt][kk][lane][16 bytes]; bias [level][mt*8 + f%8].
+extern "C" int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ks, int8_t *packed, int32_t *bias) {
+    if (!tapq || !packed || !bias) return gcs_fail(GCS_EINVAL, "gcs_bank_pack: NULL pointer");
+    int FL[GCS_LEVELS_MAX], nl;
+    if (!bank_levels(n_scales, n_orient, FL, &nl))
+        return gcs_fail(GCS_EINVAL, "gcs_bank_pack: need 1 <= n_scales <= 8 and n_orient >= 1");
+    if (ks < 1 || ks > GCS_KSIZE_MAX || (ks & 1) == 0)
+        return gcs_fail(GCS_EINVAL, "gcs_bank_pack: ksize must be odd and <= 15");
+    const int off = (GCS_KSIZE_MAX - ks) / 2; // centre smaller kernels in the 15x15 frame
+    memset(packed, 0, gcs_bank_packed_bytes(n_scales, n_orient));
+    memset(bias, 0, gcs_bank_bias_count(n_scales, n_orient) * sizeof(int32_t));
+    int mt_base = 0;
+    for (int L = 0; L < nl; ++L) {
+        const int f0 = 2 * L * n_orient;
+        for (int fl = 0; fl < FL[L]; ++fl) {
+            const int f = f0 + fl;
+            long s_re = 0, s_im = 0;
+            for (int t = 0; t < ks * ks; ++t) {
+                s_re += tapq[((size_t)f * 2 + 0) * ks * ks + t];
+                s_im += tapq[((size_t)f * 2 + 1) * ks * ks + t];
+            }
+            if (s_im != 0) return gcs_fail(GCS_EINVAL, "gcs_bank_pack: imaginary taps must sum to zero");
+            bias[mt_base * 8 + fl] = (int32_t)(128 * s_re);
+        }
+        for (int mt = 0; mt < mtiles(FL[L]); ++mt)
+            for (int kk = 0; kk < 8; ++kk)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    const int fl = 8 * mt + r / 4, part = r & 3;
+                    int8_t *dst = packed + (((size_t)(mt_base + mt) * 8 + kk) * 64 + lane) * 16;
+                    if (fl >= FL[L]) continue;
+                    const int f = f0 + fl;
+                    const int dy = 2 * kk + h - off;
+                    if (dy < 0 || dy >= ks) continue;
+                    for (int j = 0; j < 16; ++j) {
+                        const int dx = j - off;
+                        if (dx < 0 || dx >= ks) continue;
+                        const int q = tapq[(((size_t)f * 2 + (part >> 1)) * ks + dy) * ks + dx];
+                        if (q > 32639 || q < -32639)
+                            return gcs_fail(GCS_EINVAL, "gcs_bank_pack: tap outside two-digit range");
+                        const int lo = ((q + 128) & 255) - 128;
+                        const int hi = (q - lo) >> 8;
+                        dst[j] = (int8_t)((part & 1) ? hi : lo);
+                    }
+                }
+        mt_base += mtiles(FL[L]);
+    }
+    return GCS_OK;
+}

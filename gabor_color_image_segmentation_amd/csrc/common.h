@@ -1,0 +1,127 @@
+// common.h — shared by the translation units of libgcs.so (gfx950 only): error plumbing and the
+// geometry of the feature slab. Arithmetic: SPEC.md. Not part of the ABI (include/gcs.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gcs.h"
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------- errors
+int gcs_fail(int code, const char *msg);                  // records the thread-local message, returns code
+int gcs_hip_fail(hipError_t e, const char *what);
+#define GCS_CHECK_LAUNCH(what)                               \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return gcs_hip_fail(e_, what); \
+    } while (0)
+
+static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+static inline int mtiles(int F) { return (F + 7) / 8; }
+
+// ------------------------------------------------------------------------ slab geometry
+// The feature slab keeps every pyramid level at its own resolution (SPEC.md §3). The image is cut into
+// 8x8-pixel BLOCKS, numbered in raster order (blk = by * bx_n + bx, bx_n = ceil(W/8)); a block owns its
+// 8x8 level-0 pixels and their parents: 4x4 level-1, 2x2 level-2 and 1 level-3 pixel. Four consecutive
+// blocks form a TILE = the 256 pixels one k-means workgroup step handles (one block per wave). A tile is
+// ONE contiguous run of bytes:
+//     [level 0: D_0 planes x 256 u16][level 1: D_1 x 64][level 2: D_2 x 16][level 3: D_3 x 4]
+// (each level block padded to 16 bytes), pixel order inside a plane = (block in tile, row, column) of that
+// level's sub-block. Planes are in PHYSICAL order: level-major, then channel, then filter-in-level; logical
+// feature d = c*F + f (SPEC.md §3) with f = 2L*n_orient + fl. Values are stored offset-binary (x ^ 0x8080) so
+// that both bytes are signed MFMA digits. Labels use the same pixel order: [B][tile][256] uint8.
+constexpr int GCS_LEVELS_MAX = 4;
+constexpr int KP_TP = 256;            // pixels per tile = threads per k-means workgroup
+
+struct GcsLayout {
+    int H, W;                         // full-resolution image
+    int bx_n, by_n, nblk, ntiles;     // 8x8 blocks per row / column / image; tiles per image
+    int n_levels, n_orient, F, D;     // pyramid levels, orientations, filters, features (3F)
+    int FL[GCS_LEVELS_MAX];           // filters on level L
+    int DL[GCS_LEVELS_MAX];           // planes on level L (3 * FL)
+    int row0[GCS_LEVELS_MAX];         // first physical plane of level L
+    int off[GCS_LEVELS_MAX];          // byte offset of level L inside a tile
+    int HL[GCS_LEVELS_MAX], WL[GCS_LEVELS_MAX];   // level image size
+    int tile_bytes;
+};
+
+// Returns false when the shape is not representable.
+static inline bool gcs_make_layout(int H, int W, int n_scales, int n_orient, GcsLayout *lo) {
+    if (H <= 0 || W <= 0 || n_scales < 1 || n_scales > 2 * GCS_LEVELS_MAX || n_orient < 1) return false;
+    memset(lo, 0, sizeof *lo);
+    lo->H = H;
+    lo->W = W;
+    lo->bx_n = (W + 7) / 8;
+    lo->by_n = (H + 7) / 8;
+    const long long nblk = (long long)lo->bx_n * lo->by_n;
+    if (nblk > 0x3fffffffLL) return false;
+    lo->nblk = (int)nblk;
+    lo->ntiles = (lo->nblk + 3) / 4;
+    lo->n_levels = (n_scales + 1) / 2;
+    lo->n_orient = n_orient;
+    const long long F = (long long)n_scales * n_orient;
+    if (F > 21845) return false;      // D = 3F must fit the uint16 plane indices used on the host side
+    lo->F = (int)F;
+    lo->D = 3 * lo->F;
+    int row = 0, off = 0, h = H, w = W;
+    for (int L = 0; L < lo->n_levels; ++L) {
+        const int scales = n_scales - 2 * L >= 2 ? 2 : 1;
+        lo->FL[L] = scales * n_orient;
+        lo->DL[L] = 3 * lo->FL[L];
+        lo->row0[L] = row;
+        lo->off[L] = off;
+        lo->HL[L] = h;
+        lo->WL[L] = w;
+        row += lo->DL[L];
+        off += round_up(lo->DL[L] * (KP_TP >> (2 * L)) * 2, 16);
+        h = (h + 1) / 2;
+        w = (w + 1) / 2;
+    }
+    lo->tile_bytes = off;
+    return true;
+}
+
+// physical plane -> (level, plane in level); logical feature <-> physical plane
+__host__ __device__ __forceinline__ int gcs_level_of_plane(const GcsLayout &lo, int r) {
+    int L = 0;
+#pragma unroll
+    for (int i = 1; i < GCS_LEVELS_MAX; ++i)
+        if (i < lo.n_levels && r >= lo.row0[i]) L = i;
+    return L;
+}
+__host__ __device__ __forceinline__ int gcs_logical_of_plane(const GcsLayout &lo, int r) {
+    const int L = gcs_level_of_plane(lo, r);
+    const int ri = r - lo.row0[L];
+    const int c = ri / lo.FL[L], fl = ri - c * lo.FL[L];
+    return c * lo.F + 2 * L * lo.n_orient + fl;
+}
+__host__ __device__ __forceinline__ int gcs_plane_of_logical(const GcsLayout &lo, int d) {
+    const int c = d / lo.F, f = d - c * lo.F;
+    const int L = (f / lo.n_orient) >> 1;
+    return lo.row0[L] + c * lo.FL[L] + (f - 2 * L * lo.n_orient);
+}
+
+// Byte offset (from the slab base) of the value of physical plane r at FULL-resolution pixel (y, x) of image b:
+// the level-L parent (y >> L, x >> L) inside the pixel's block.
+__device__ __forceinline__ size_t gcs_slab_offset(const GcsLayout &lo, int b, int r, int y, int x) {
+    const int L = gcs_level_of_plane(lo, r);
+    const int blk = (y >> 3) * lo.bx_n + (x >> 3);
+    const int side = 8 >> L;                                          // sub-block side at level L
+    const int iy = (y & 7) >> L, ix = (x & 7) >> L;
+    const int npl = KP_TP >> (2 * L);                                 // pixels per plane of a tile at level L
+    return ((size_t)b * lo.ntiles + (blk >> 2)) * lo.tile_bytes + lo.off[L] +
+           ((size_t)(r - lo.row0[L]) * npl + (blk & 3) * side * side + iy * side + ix) * 2;
+}
+
+// Partial sums, element-major: [set][element i of k*(D+1)][rows of that set] uint64, rows = the workgroups that
+// contribute to the set (per-image codebooks: the image's `parts`; one codebook: all gridDim.y * parts). The
+// values an output element is summed from are then one contiguous run for kmeans_reduce_kernel.
+__device__ __forceinline__ size_t partial_index(int per_image, int b, int part, int parts, int i, int row_len) {
+    return per_image ? ((size_t)b * row_len + i) * parts + part
+                     : (size_t)i * ((size_t)gridDim.y * parts) + (size_t)b * parts + part;
+}

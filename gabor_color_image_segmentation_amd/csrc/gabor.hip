@@ -1,0 +1,471 @@
+// gabor.hip — SPEC.md §3 on gfx950: pyramid levels, reflect-padded planes, the filter bank as an im2col GEMM on
+// v_mfma_i32_32x32x32_i8 with a fused magnitude epilogue, and the slab -> canonical tensor unpacker.
+// The reference ships no code for this path; slot: /root/reference/BSD_metrics/script.py:30.
+//
+// Kernels
+//   gabor_pad_kernel        level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised.
+//   gabor_down_pad_kernel   level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
+//                           padded plane of level L and, when a further level follows, as a compact image.
+//   gabor_mfma_kernel       one pyramid level: A = packed 2-digit int8 taps of the level's filters (rows = filter x
+//                           {re_lo,re_hi,im_lo,im_hi}, resident in registers), B = (pixel-128) windows built from an LDS
+//                           tile (LDS-DMA double buffer) by dword reads + v_alignbit, exact int32 accumulate, fused
+//                           epilogue (digit recombine, >>shift, |.|^2, exact isqrt) -> the level's part of the slab.
+// Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
+#include "common.h"
+
+constexpr int G_TW = 64;            // output tile width  (8 lanes-in-x * 8 shifts)
+constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
+constexpr int G_HALO = 7;
+constexpr int G_LROWS = G_TH + 15;  // 47 rows: halo 14 + the zero-tap row 15
+constexpr int G_LPITCH = 96;        // bytes per LDS tile row (>= 64 + 16 + 12)
+
+// scipy.ndimage mode='reflect' (d c b a | a b c d | d c b a) at any distance (SPEC.md §3)
+__device__ __forceinline__ int reflect(int i, int n) {
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+// floor(sqrt(n)) for n <= 2 * 32642^2 < 2^31 (SPEC.md §3 bound), exact, in 7 VALU ops
+// (measured on gfx950, tools/ubench/valu_ops2: v_cvt_u32_f32 ~3 ns and v_cmp+v_addc ~4.3 ns per
+// wave-instruction, against ~1.2 ns for an add):
+//   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
+//   bits = r + 2^23 (as uint)          the sum has ulp 1: bits = 0x4B000000 + RNE(r), RNE(r) in {floor(s), floor(s)+1}
+//   qr^2 = v_mul_u32_u24(bits, bits)   the multiplier only sees the low 24 bits, i.e. qr = RNE(r) (< 2^16)
+//   q    = qr - (qr^2 > n)             sign arithmetic, one v_add3: bits - 0x4B000000 + ((int)(n - qr^2) >> 31);
+//                                      qr <= 46164 so qr^2 < 2^31 and the signed difference cannot overflow.
+// Exhaustively checked over the whole domain by tests/test_gpu_parity.py::test_isqrt31_exhaustive.
+__device__ __forceinline__ unsigned isqrt31(unsigned n) {
+    const unsigned bits = __float_as_uint(__builtin_amdgcn_sqrtf((float)n) + 8388608.0f);
+    const int d = (int)(n - __umul24(bits, bits));
+    return bits - 0x4B000000u + (unsigned)(d >> 31);
+}
+
+// out[i] = 1 if isqrt31 is wrong anywhere in [i * chunk, (i+1) * chunk) ∩ [0, n_max] (test hook; SPEC.md §3 domain)
+__global__ void isqrt31_check_kernel(unsigned n_max, unsigned chunk, unsigned *__restrict__ bad) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long lo = (unsigned long long)i * chunk;
+    unsigned wrong = 0;
+    for (unsigned long long n = lo; n < lo + chunk && n <= n_max; ++n) {
+        const unsigned long long q = isqrt31((unsigned)n);
+        wrong |= (q * q > n) | ((q + 1) * (q + 1) <= n);
+    }
+    if (wrong) atomicAdd(bad, 1u);
+}
+
+extern "C" int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_t stream) {
+    if (!bad_dev) return gcs_fail(GCS_EINVAL, "gcs_selftest_isqrt: NULL pointer");
+    const unsigned chunk = 4096;
+    const unsigned threads = n_max / chunk + 1;
+    hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return gcs_hip_fail(e, "gcs_selftest_isqrt(memset)");
+    hipLaunchKernelGGL(isqrt31_check_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, n_max, chunk, bad_dev);
+    GCS_CHECK_LAUNCH("gcs_selftest_isqrt");
+    return GCS_OK;
+}
+
+// Level 0 pre-pass: interleaved uint8 RGB -> planar (pixel - 128) int8 with the reflect border and
+// the tile over-read already materialised: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128
+// for r < tiles_y*32 + 15, u < tiles_x*64 + 32. The main kernel then stages tiles with aligned
+// 16-byte copies and no index arithmetic. ~26 B of extra HBM traffic per pixel-channel row: noise.
+__global__ __launch_bounds__(256) void gabor_pad_kernel(const uint8_t *__restrict__ img, int H, int W, int Hp,
+                                                        int Wp, int8_t *__restrict__ planes) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int gy = reflect(r - G_HALO, H);
+    const uint8_t *row = img + ((size_t)b * H + gy) * W * 3;
+    for (int u4 = blockIdx.x * blockDim.x + threadIdx.x; u4 < Wp / 4; u4 += gridDim.x * blockDim.x) {
+        unsigned o[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gx = reflect(4 * u4 + e - G_HALO, W);
+            const uint8_t *p = row + (size_t)gx * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] |= (unsigned)(p[c] ^ 0x80) << (8 * e);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
+    }
+}
+
+// Level L >= 1 (SPEC.md §3 pyramid): I_L[y][x] = (sum of the 2x2 block of I_{L-1}, indices clamped to the last
+// row / column, + 2) >> 2, evaluated at the reflected coordinates of the padded plane. SRC_RGB: I_{L-1} is the
+// interleaved input image (L == 1), otherwise the compact planar level image [B][3][Hs][Ws] written by the previous
+// launch. `img_out` (may be NULL): compact planar I_L for the next level.
+template <bool SRC_RGB>
+__global__ __launch_bounds__(256) void gabor_down_pad_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL,
+                                                             int WL, int Hp, int Wp, int8_t *__restrict__ planes,
+                                                             uint8_t *__restrict__ img_out) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int ly = reflect(r - G_HALO, HL);
+    const int y0 = 2 * ly, y1 = min(2 * ly + 1, Hs - 1);
+    for (int u4 = blockIdx.x * blockDim.x + threadIdx.x; u4 < Wp / 4; u4 += gridDim.x * blockDim.x) {
+        unsigned o[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = 4 * u4 + e;
+            const int lx = reflect(u - G_HALO, WL);
+            const int x0 = 2 * lx, x1 = min(2 * lx + 1, Ws - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                unsigned s;
+                if (SRC_RGB) {
+                    const uint8_t *p0 = src + ((size_t)b * Hs + y0) * Ws * 3 + c, *p1 = src + ((size_t)b * Hs + y1) * Ws * 3 + c;
+                    s = p0[(size_t)x0 * 3] + p0[(size_t)x1 * 3] + p1[(size_t)x0 * 3] + p1[(size_t)x1 * 3];
+                } else {
+                    const uint8_t *p0 = src + (((size_t)b * 3 + c) * Hs + y0) * Ws, *p1 = src + (((size_t)b * 3 + c) * Hs + y1) * Ws;
+                    s = p0[x0] + p0[x1] + p1[x0] + p1[x1];
+                }
+                const unsigned m = (s + 2u) >> 2;
+                o[c] |= (m ^ 0x80u) << (8 * e);
+                if (img_out && r >= G_HALO && r - G_HALO < HL && u >= G_HALO && u - G_HALO < WL)
+                    img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (u - G_HALO)] = (uint8_t)m;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
+    }
+}
+
+#ifndef GCS_GABOR_WAVES
+#define GCS_GABOR_WAVES 2
+#endif
+constexpr int GCS_GABOR_MTMAX = 2;   // row tiles per launch: 3 needs ~250 VGPRs at 2 waves/SIMD and spills (measured slower)
+
+// One pyramid level. MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that
+// exist in the last row tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
+template <int MT, int GLAST>
+__global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
+    const int8_t *__restrict__ planes, int HL, int Hp, int Wp, const int8_t *__restrict__ apack,
+    const int32_t *__restrict__ bias, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int pitchL,
+    int tiles_x, int tiles_per_image, int total_tiles, int L, int bx_n, int ntiles, int tile_bytes, int offL) {
+    // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
+    // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
+    // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
+    // 846 16-byte chunks, i.e. exactly the lane-linear destination LDS-DMA wants.
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][3][G_LROWS][G_LPITCH];
+    constexpr int NCHUNK = 3 * G_LROWS * (G_LPITCH / 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    auto stage_tile = [&](int tile, int buf) {
+        const int b_ = tile / tiles_per_image, rem = tile % tiles_per_image;
+        const int y0_ = (rem / tiles_x) * G_TH, x0_ = (rem % tiles_x) * G_TW;
+        const int8_t *src0 = planes + ((size_t)b_ * 3 * Hp + y0_) * Wp + x0_;
+#pragma unroll
+        for (int k = 0; k < (NCHUNK + 255) / 256; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NCHUNK) {
+                const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
+                const int row = rc % G_LROWS, c = rc / G_LROWS;
+                const int8_t *g = src0 + ((size_t)c * Hp + row) * Wp + 16 * ch16;
+                // LDS destination: wave-uniform base (this wave's first chunk) + lane * 16
+                int8_t *l = &s_tile[buf][0][0][0] + 16 * (256 * k + 64 * wave);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)g,
+                    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- the whole A operand lives in registers: MT x 8 lane-linear 16-byte fragments
+    v4i afr[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            afr[mt][kk] = reinterpret_cast<const v4i *>(apack)[((size_t)mt * 8 + kk) * 64 + lane];
+
+    // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
+    // for a pixel shift s = 4*qq + t in 0..7. A lane therefore ends up owning 8 consecutive
+    // pixels (16 bytes) per filter: one row of an 8x8 block of the slab.
+    const int r = lane & 31, h = lane >> 5;
+    const int li = r & 7, lyy = r >> 3;
+
+    int bias_v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_v[mt][g] = bias[8 * mt + 2 * g + h];
+
+    // slab geometry of this level (csrc/common.h): sub-block side 8 >> L, 2^L blocks under a lane's 8 pixels
+    const int side_sh = 3 - L;
+    const int npl = KP_TP >> (2 * L);               // pixels per plane of a tile at this level
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) stage_tile(tile, 0);
+    __syncthreads();                       // drains the LDS-DMA (vmcnt) and orders it for every wave
+    for (int it = 0; tile < total_tiles; tile += gridDim.x, ++it) {
+      const int buf = it & 1;
+      if (tile + (int)gridDim.x < total_tiles) stage_tile(tile + gridDim.x, buf ^ 1);
+      const int b = tile / tiles_per_image, trem = tile % tiles_per_image;
+      const int y0 = (trem / tiles_x) * G_TH, x0 = (trem % tiles_x) * G_TW;
+      if (y0 + wave * 8 < HL) {            // waves wholly below the image skip the work, not the barrier
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+        for (int rb = 0; rb < 2; ++rb) {       // two 4-row blocks per wave
+            if (y0 + wave * 8 + rb * 4 >= HL) break;   // block wholly below the image (H = 321: 1 row in the last tile row)
+            const int trow = wave * 8 + rb * 4 + lyy;
+            unsigned outp[MT][4][4];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 8*li + 4*qq
+                int win[8][5];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int *rp = reinterpret_cast<const int *>(&s_tile[buf][c][trow + 2 * kk + h][8 * li + 4 * qq]);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v16i acc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[mt][e] = 0;   // inline-constant C of the first MFMA
+                    // the wave inside its MFMA chain outranks the one in its (pure VALU) epilogue: -2.5 % (A/B)
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
+                        v4i bf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            bf[j] = (t == 0) ? win[kk][j]       // v_alignbit_b32: same result as v_alignbyte, 2.4x the rate
+                                             : (int)__builtin_amdgcn_alignbit((unsigned)win[kk][j + 1],
+                                                                              (unsigned)win[kk][j], 8 * t);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter.
+                    // All magnitudes are computed as independent chains (ILP), then pinned.
+                    unsigned mag[MT][4];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            if (mt == MT - 1 && g >= GLAST) continue;
+                            // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22), not a shift (slow here)
+                            const int a_re = (__mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
+                            const int a_im = (__mul24(acc[mt][4 * g + 3], 256) + acc[mt][4 * g + 2]) >> shift;
+                            const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                            mag[mt][g] = isqrt31(n);
+                        }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            if (mt == MT - 1 && g >= GLAST) continue;
+                            unsigned &o = outp[mt][g][2 * qq + (t >> 1)];
+                            if ((t & 1) == 0)
+                                o = mag[mt][g];
+                            else
+                                o = __umul24(mag[mt][g], 65536u) + o;      // pack the odd pixel into the high half
+                            // materialise now: otherwise hipcc sinks the whole epilogue into the
+                            // store branches and keeps every accumulator live until then
+                            asm volatile("" : "+v"(o));
+                        }
+                    // keep hipcc from building all four shifts' fragments up front
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy. Level 0: one row of one 8x8 block = one 16-byte
+            // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels).
+            const int oy = y0 + trow, ox = x0 + 8 * li;
+            if (oy < HL && ox < pitchL) {
+                const int by = oy >> side_sh, iy = oy & ((1 << side_sh) - 1);
+                const int bx0 = ox >> side_sh;
+                unsigned char *img_base = feats + (size_t)b * ntiles * tile_bytes + offL;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (mt == MT - 1 && g >= GLAST) continue;
+                        const int f = fbase + 8 * mt + 2 * g + h;      // filter index inside the level
+                        if (f >= FLv) continue;
+                        // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
+                        // signed MFMA digits for the k-means pass, which stages them untouched
+                        const unsigned w0 = outp[mt][g][0] ^ 0x80808080u, w1 = outp[mt][g][1] ^ 0x80808080u,
+                                       w2 = outp[mt][g][2] ^ 0x80808080u, w3 = outp[mt][g][3] ^ 0x80808080u;
+                        const size_t plane_off = (size_t)(c * FLv + f) * npl * 2 + (size_t)(iy << side_sh) * 2;
+                        auto dst = [&](int p) -> unsigned char * {     // block bx0 + p, this lane's row inside it
+                            const int blk = by * bx_n + bx0 + p;
+                            return img_base + (size_t)(blk >> 2) * tile_bytes + plane_off +
+                                   (size_t)((blk & 3) << (2 * side_sh)) * 2;
+                        };
+                        if (L == 0) {
+                            *reinterpret_cast<uint4 *>(dst(0)) = make_uint4(w0, w1, w2, w3);
+                        } else if (L == 1) {
+                            *reinterpret_cast<uint2 *>(dst(0)) = make_uint2(w0, w1);
+                            if (bx0 + 1 < bx_n) *reinterpret_cast<uint2 *>(dst(1)) = make_uint2(w2, w3);
+                        } else if (L == 2) {
+                            const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+                            for (int p = 0; p < 4; ++p)
+                                if (bx0 + p < bx_n) *reinterpret_cast<unsigned *>(dst(p)) = w[p];
+                        } else {
+                            const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+                            for (int p = 0; p < 8; ++p)
+                                if (bx0 + p < bx_n)
+                                    *reinterpret_cast<uint16_t *>(dst(p)) = (uint16_t)(w[p >> 1] >> (16 * (p & 1)));
+                        }
+                    }
+            }
+        }
+    }
+      }
+      __syncthreads();   // next tile landed (vmcnt drained) and this buffer is free to refill
+    }
+}
+
+// ------------------------------------------------------------------------------ workspace
+static inline int gabor_hp(int H) { return (H + G_TH - 1) / G_TH * G_TH + 15; }
+static inline int gabor_wp(int W) { return (W + G_TW - 1) / G_TW * G_TW + 32; }
+
+struct GaborWs {
+    size_t plane_off[GCS_LEVELS_MAX];   // padded planes [B][3][Hp][Wp] int8 of level L
+    size_t img_off[GCS_LEVELS_MAX];     // compact planar image [B][3][HL][WL] uint8 of level L (1 <= L <= n_levels-2)
+    int Hp[GCS_LEVELS_MAX], Wp[GCS_LEVELS_MAX], HL[GCS_LEVELS_MAX], WL[GCS_LEVELS_MAX];
+    size_t total;
+};
+static GaborWs gabor_ws(int B, int H, int W, int n_levels) {
+    GaborWs ws{};
+    size_t off = 0;
+    int h = H, w = W;
+    for (int L = 0; L < n_levels; ++L) {
+        ws.HL[L] = h;
+        ws.WL[L] = w;
+        ws.Hp[L] = gabor_hp(h);
+        ws.Wp[L] = gabor_wp(w);
+        ws.plane_off[L] = off;
+        off += ((size_t)B * 3 * ws.Hp[L] * ws.Wp[L] + 255) / 256 * 256;
+        if (L >= 1 && L + 1 < n_levels) {
+            ws.img_off[L] = off;
+            off += ((size_t)B * 3 * h * w + 255) / 256 * 256;
+        }
+        h = (h + 1) / 2;
+        w = (w + 1) / 2;
+    }
+    ws.total = off;
+    return ws;
+}
+
+extern "C" size_t gcs_gabor_workspace_bytes(int B, int H, int W, int n_scales) {
+    if (B <= 0 || H <= 0 || W <= 0 || n_scales < 1 || n_scales > GCS_SCALES_MAX) return 0;
+    return gabor_ws(B, H, W, (n_scales + 1) / 2).total;
+}
+
+extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const int8_t *packed,
+                                  const int32_t *bias, int n_scales, int n_orient, int shift, void *workspace,
+                                  uint16_t *feats, gcs_stream_t stream) {
+    if (!img || !packed || !bias || !feats || !workspace)
+        return gcs_fail(GCS_EINVAL, "gcs_gabor_features: NULL pointer");
+    if (B <= 0) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: B must be > 0");
+    if (H < 8 || W < 8) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H and W must be >= 8");
+    if (shift < 0 || shift > 23) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: shift out of range");
+    if (B > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: B too large for one launch");
+    GcsLayout lo;
+    if (!gcs_make_layout(H, W, n_scales, n_orient, &lo))
+        return gcs_fail(GCS_EINVAL, "gcs_gabor_features: need 1 <= n_scales <= 8, n_orient >= 1");
+    if ((long long)B * lo.ntiles * lo.tile_bytes > 0x7fffffffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: slab too large");
+    const GaborWs ws = gabor_ws(B, H, W, lo.n_levels);
+    if (ws.Hp[0] > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
+    unsigned char *wsb = static_cast<unsigned char *>(workspace);
+    const dim3 block(256);
+    int mt_base = 0;
+    for (int L = 0; L < lo.n_levels; ++L) {
+        int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
+        const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
+        const dim3 pgrid((Wp / 4 + 255) / 256, Hp, B);
+        if (L == 0) {
+            hipLaunchKernelGGL(gabor_pad_kernel, pgrid, block, 0, stream, img, H, W, Hp, Wp, planes);
+        } else {
+            uint8_t *img_out = L + 1 < lo.n_levels ? wsb + ws.img_off[L] : nullptr;
+            if (L == 1)
+                hipLaunchKernelGGL((gabor_down_pad_kernel<true>), pgrid, block, 0, stream, img, H, W, HL, WL, Hp, Wp,
+                                   planes, img_out);
+            else
+                hipLaunchKernelGGL((gabor_down_pad_kernel<false>), pgrid, block, 0, stream,
+                                   (const uint8_t *)(wsb + ws.img_off[L - 1]), ws.HL[L - 1], ws.WL[L - 1], HL, WL, Hp,
+                                   Wp, planes, img_out);
+        }
+        GCS_CHECK_LAUNCH("gcs_gabor_features(pad)");
+        const int tiles_x = (WL + G_TW - 1) / G_TW, tiles_y = (HL + G_TH - 1) / G_TH;
+        const int tiles_per_image = tiles_x * tiles_y;
+        const long long total_ll = (long long)tiles_per_image * B;
+        if (total_ll > 0x7fffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
+        const int total_tiles = (int)total_ll;
+        const int pitchL = round_up(WL, 8);
+        const int MT = mtiles(lo.FL[L]);
+        for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
+            const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
+            // filters of this launch: [8*mt0, min(FL, 8*(mt0+n))) of the level (planes c*FL + f)
+            const int fl_here = lo.FL[L] - 8 * mt0 < 8 * n ? lo.FL[L] - 8 * mt0 : 8 * n;
+            const int glast = (fl_here - 8 * (n - 1) + 1) / 2;
+            // persistent grid: one workgroup per resident slot (2 per CU at MT >= 2, 3 at MT == 1)
+            const int slots = 256 * (n == 1 ? 3 : 2);
+            const dim3 grid(total_tiles < slots ? total_tiles : slots);
+            const int8_t *ap = packed + (size_t)(mt_base + mt0) * 8 * 64 * 16;
+            const int32_t *bp = bias + (size_t)(mt_base + mt0) * 8;
+#define GCS_GABOR_LAUNCH(MT_, GL_)                                                                                 \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp, lo.FL[L], \
+                       8 * mt0, shift, reinterpret_cast<unsigned char *>(feats), pitchL, tiles_x, tiles_per_image,          \
+                       total_tiles, L, lo.bx_n, lo.ntiles, lo.tile_bytes, lo.off[L])
+            if (n == 2) {
+                switch (glast) {
+                case 1: GCS_GABOR_LAUNCH(2, 1); break;
+                case 2: GCS_GABOR_LAUNCH(2, 2); break;
+                case 3: GCS_GABOR_LAUNCH(2, 3); break;
+                default: GCS_GABOR_LAUNCH(2, 4); break;
+                }
+            } else {
+                switch (glast) {
+                case 1: GCS_GABOR_LAUNCH(1, 1); break;
+                case 2: GCS_GABOR_LAUNCH(1, 2); break;
+                case 3: GCS_GABOR_LAUNCH(1, 3); break;
+                default: GCS_GABOR_LAUNCH(1, 4); break;
+                }
+            }
+#undef GCS_GABOR_LAUNCH
+            GCS_CHECK_LAUNCH("gcs_gabor_features");
+        }
+        mt_base += MT;
+    }
+    return GCS_OK;
+}
+
+// ------------------------------------------------------------------------------- unpack
+// Slab -> canonical [B][D][H][W] uint16 of SPEC.md §3 (level-L responses replicated over 2^L blocks).
+__global__ void unpack_kernel(const unsigned char *__restrict__ feats, GcsLayout lo, size_t planes,
+                              uint16_t *__restrict__ out) {
+    const size_t hw = (size_t)lo.H * lo.W;
+    const size_t n = planes * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pl = i / hw;
+        const int rem = (int)(i % hw);
+        const int b = (int)(pl / lo.D), d = (int)(pl % lo.D);
+        const uint16_t v = *reinterpret_cast<const uint16_t *>(
+            feats + gcs_slab_offset(lo, b, gcs_plane_of_logical(lo, d), rem / lo.W, rem % lo.W));
+        out[i] = v ^ 0x8080u;
+    }
+}
+
+extern "C" int gcs_features_unpack(const uint16_t *feats, int B, int H, int W, int n_scales, int n_orient,
+                                   uint16_t *out, gcs_stream_t stream) {
+    if (!feats || !out) return gcs_fail(GCS_EINVAL, "gcs_features_unpack: NULL pointer");
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo))
+        return gcs_fail(GCS_EINVAL, "gcs_features_unpack: bad shape");
+    hipLaunchKernelGGL(unpack_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<const unsigned char *>(feats),
+                       lo, (size_t)B * lo.D, out);
+    GCS_CHECK_LAUNCH("gcs_features_unpack");
+    return GCS_OK;
+}

@@ -1,0 +1,737 @@
+// kmeans.hip — SPEC.md §4 on gfx950 over the pyramid feature slab (csrc/common.h).
+// The reference ships no code for this path; slot: /root/reference/BSD_metrics/script.py:30.
+//
+// Kernels
+//   kmeans_pass_mfma_kernel  one Lloyd pass (assign + update) on the matrix cores for D <= 207; HBM-bound stream of the
+//                            slab, which keeps pyramid level L at 1/4^L of the pixels: a tile's coarse planes are
+//                            replicated over their 2^L x 2^L blocks while they are staged into LDS.
+//   kmeans_assign_kernel     generic pass for D >= 208: exact integer argmin via fp32 byte-digit FMAs (all partial
+//                            sums < 2^24, hence exact), LDS-replicated u32 accumulators.
+//   kmeans_reduce_kernel     element-major partial sums -> int64 sums (+ the centroid update when single-rank).
+//   kmeans_finalize / init / features_gather / labels_widen / labels_raster: small helpers.
+// Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
+#include "common.h"
+
+#define LAYOUT_OR_FAIL(lo, who)                                        \
+    GcsLayout lo;                                                      \
+    if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo))     \
+        return gcs_fail(GCS_EINVAL, who ": bad shape or bank")
+
+// ------------------------------------------------------------------------ init / gather
+__global__ void kmeans_init_kernel(const unsigned char *__restrict__ feats, GcsLayout lo, int k,
+                                   uint16_t *__restrict__ cent) {
+    const int set = blockIdx.x; // image index == set index (n_sets == 1 -> image 0)
+    const long P = (long)lo.H * lo.W;
+    for (int i = threadIdx.x; i < k * lo.D; i += blockDim.x) {
+        const int j = i / lo.D, d = i % lo.D;
+        const long p = ((2L * j + 1) * P) / (2L * k);
+        const int y = (int)(p / lo.W), x = (int)(p % lo.W);
+        cent[((size_t)set * k + j) * lo.D + d] =
+            *reinterpret_cast<const uint16_t *>(feats + gcs_slab_offset(lo, set, gcs_plane_of_logical(lo, d), y, x)) ^ 0x8080u;
+    }
+}
+
+extern "C" int gcs_kmeans_init(const uint16_t *feats, int B, int H, int W, int n_scales, int n_orient, int k,
+                               int n_sets, uint16_t *cent, gcs_stream_t stream) {
+    if (!feats || !cent) return gcs_fail(GCS_EINVAL, "gcs_kmeans_init: NULL pointer");
+    LAYOUT_OR_FAIL(lo, "gcs_kmeans_init");
+    if (k < 1 || k > GCS_K_MAX) return gcs_fail(GCS_EINVAL, "gcs_kmeans_init: k must be in 1..16");
+    if (n_sets != 1 && n_sets != B) return gcs_fail(GCS_EINVAL, "gcs_kmeans_init: n_sets must be 1 or B");
+    hipLaunchKernelGGL(kmeans_init_kernel, dim3(n_sets), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned char *>(feats), lo, k, cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_init");
+    return GCS_OK;
+}
+
+// out[i][d] = feature d of pixel (b, y, x) = byx[i]; b < 0 gives a zero row. Lets a rank publish the
+// SPEC.md §4 init centroids it owns when an image is sharded by rows (BASELINE config 5).
+__global__ void features_gather_kernel(const unsigned char *__restrict__ feats, GcsLayout lo, int n,
+                                       const int32_t *__restrict__ byx, uint16_t *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * lo.D; i += gridDim.x * blockDim.x) {
+        const int r = i / lo.D, d = i % lo.D;
+        const int b = byx[3 * r], y = byx[3 * r + 1], x = byx[3 * r + 2];
+        out[i] = b < 0 ? (uint16_t)0
+                       : (uint16_t)(*reinterpret_cast<const uint16_t *>(
+                                        feats + gcs_slab_offset(lo, b, gcs_plane_of_logical(lo, d), y, x)) ^ 0x8080u);
+    }
+}
+
+extern "C" int gcs_features_gather(const uint16_t *feats, int B, int H, int W, int n_scales, int n_orient, int n,
+                                   const int32_t *byx, uint16_t *out, gcs_stream_t stream) {
+    if (!feats || !byx || !out) return gcs_fail(GCS_EINVAL, "gcs_features_gather: NULL pointer");
+    LAYOUT_OR_FAIL(lo, "gcs_features_gather");
+    if (n <= 0) return gcs_fail(GCS_EINVAL, "gcs_features_gather: n must be > 0");
+    hipLaunchKernelGGL(features_gather_kernel, dim3((n * lo.D + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned char *>(feats), lo, n, byx, out);
+    GCS_CHECK_LAUNCH("gcs_features_gather");
+    return GCS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic pass (D >= 208). Exact integer argmin with fp32 digit arithmetic: x = 256*xh + xl, c = 256*ch + cl (bytes);
+//   sum_d x*c = 65536*sum xh*ch + 256*sum (xh*cl + xl*ch) + sum xl*cl,
+// every partial sum stays below 2^24 over a chunk of <= 128 planes, so fp32 FMA is exact.
+// score_j = |c_j|^2 - 2 sum_d x_d c_jd (the |x|^2 term is common to all j). Planes are walked in PHYSICAL order
+// (level-major); the centroid digits are permuted to match when they are loaded.
+constexpr int KM_CHUNK = 128;
+
+// two horizontally adjacent pixels (x even) of physical plane r: one aligned dword on level 0, the same parent twice above
+__device__ __forceinline__ unsigned feature_pair(const unsigned char *feats, const GcsLayout &lo, int b, int r, int y, int x) {
+    const unsigned char *p = feats + gcs_slab_offset(lo, b, r, y, x);
+    if (r < lo.DL[0]) return *reinterpret_cast<const unsigned *>(p) ^ 0x80808080u;
+    const unsigned v = *reinterpret_cast<const uint16_t *>(p) ^ 0x8080u;
+    return v | (v << 16);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(
+    const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int per_image, int parts,
+    int R, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: cdig float [D][K][2] | cnorm int64 [K] | acc u32 [K][D+1][R]
+    const int D = lo.D, H = lo.H, W = lo.W;
+    float *cdig = reinterpret_cast<float *>(smem);
+    long long *cnorm = reinterpret_cast<long long *>(smem + (((size_t)D * K * 2 * 4 + 15) & ~(size_t)15));
+    unsigned *acc = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(cnorm) + ((K * 8 + 15) & ~15));
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
+    const int D1 = D + 1;
+
+    for (int i = tid; i < K * D; i += 256) {
+        const int j = i / D, r = i % D;                      // r = physical plane
+        const unsigned cv = cset[j * D + gcs_logical_of_plane(lo, r)];
+        cdig[(r * K + j) * 2 + 0] = (float)(cv & 255u);
+        cdig[(r * K + j) * 2 + 1] = (float)(cv >> 8);
+    }
+    if (tid < K) {
+        long long s = 0;
+        for (int d = 0; d < D; ++d) {
+            const long long cv = cset[tid * D + d];
+            s += cv * cv;
+        }
+        cnorm[tid] = s;
+    }
+    for (int i = tid; i < K * D1 * R; i += 256) acc[i] = 0u;
+    __syncthreads();
+
+    const int ppr = (W + 1) >> 1; // pixel pairs per row
+    const long npairs = (long)H * ppr;
+    const int rep = tid & (R - 1);
+
+    for (long q = (long)part * 256 + tid; q < npairs; q += (long)parts * 256) {
+        const int y = (int)(q / ppr), x = 2 * (int)(q % ppr);
+        long long S[2][K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) S[0][j] = S[1][j] = 0;
+        for (int d0 = 0; d0 < D; d0 += KM_CHUNK) {
+            const int d1 = min(D, d0 + KM_CHUNK);
+            float a0[2][K], a1[2][K], a2[2][K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) a0[0][j] = a0[1][j] = a1[0][j] = a1[1][j] = a2[0][j] = a2[1][j] = 0.f;
+            for (int d = d0; d < d1; ++d) {
+                const unsigned u = feature_pair(feats, lo, b, d, y, x);
+                const float xl0 = (float)(u & 255u), xh0 = (float)((u >> 8) & 255u);
+                const float xl1 = (float)((u >> 16) & 255u), xh1 = (float)(u >> 24);
+                const float *cd = cdig + d * K * 2;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float cl = cd[2 * j], ch = cd[2 * j + 1];
+                    a0[0][j] = fmaf(xl0, cl, a0[0][j]);
+                    a1[0][j] = fmaf(xh0, cl, fmaf(xl0, ch, a1[0][j]));
+                    a2[0][j] = fmaf(xh0, ch, a2[0][j]);
+                    a0[1][j] = fmaf(xl1, cl, a0[1][j]);
+                    a1[1][j] = fmaf(xh1, cl, fmaf(xl1, ch, a1[1][j]));
+                    a2[1][j] = fmaf(xh1, ch, a2[1][j]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    S[p][j] += ((long long)(unsigned)a2[p][j] << 16) + ((long long)(unsigned)a1[p][j] << 8) +
+                               (long long)(unsigned)a0[p][j];
+        }
+        int lab[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            long long best = cnorm[0] - 2 * S[p][0];
+            int bj = 0;
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                const long long sc = cnorm[j] - 2 * S[p][j];
+                if (sc < best) {
+                    best = sc;
+                    bj = j;
+                }
+            }
+            lab[p] = bj;
+        }
+        {   // label slab: same pixel order as the feature slab (tile, block in tile, row, column)
+            const int blk = (y >> 3) * lo.bx_n + (x >> 3);
+            uint8_t *lp = labels + ((size_t)b * lo.ntiles + (blk >> 2)) * KP_TP + (blk & 3) * 64 + (y & 7) * 8 + (x & 7);
+            *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(lab[0] | (lab[1] << 8));
+        }
+        // accumulate (second pass over this thread's planes; L2-resident)
+        const bool rows_ok = y >= row_lo && y < row_hi;
+        const bool v0 = rows_ok && x < W, v1 = rows_ok && x + 1 < W;
+        if (v0) {
+            unsigned *a_0 = acc + (size_t)lab[0] * D1 * R + rep;
+            unsigned *a_1 = acc + (size_t)lab[1] * D1 * R + rep;
+            if (v1 && lab[0] == lab[1]) {
+                for (int d = 0; d < D; ++d) {
+                    const unsigned u = feature_pair(feats, lo, b, d, y, x);
+                    atomicAdd(a_0 + d * R, (u & 0xffffu) + (u >> 16));
+                }
+                atomicAdd(a_0 + D * R, 2u);
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const unsigned u = feature_pair(feats, lo, b, d, y, x);
+                    atomicAdd(a_0 + d * R, u & 0xffffu);
+                    if (v1) atomicAdd(a_1 + d * R, u >> 16);
+                }
+                atomicAdd(a_0 + D * R, 1u);
+                if (v1) atomicAdd(a_1 + D * R, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * D1; i += 256) {
+        const int j = i / D1, e = i % D1;                   // e = logical feature (or D = count)
+        const int pe = e < D ? gcs_plane_of_logical(lo, e) : D;
+        uint64_t s = 0;
+        for (int rr = 0; rr < R; ++rr) s += acc[((size_t)j * D1 + pe) * R + rr];
+        partials[partial_index(per_image, b, part, parts, i, K * D1)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One Lloyd pass on the matrix cores (D <= 207: 80-row LDS tile for D <= 79, 208-row tile above).
+// Per 256-pixel tile (four 8x8 blocks, one per wave), staged ONCE in LDS as D rows of 256 u16 (each byte offset by
+// -128 so it is a signed MFMA digit; rows in PHYSICAL plane order, coarse levels replicated to full resolution):
+//   assign:  scores[(j,pat)][px] = A_pat[(j,pat)][k] * X[k][px] on v_mfma_i32_32x32x32_i8, k =
+//            (plane, byte). Patterns per cluster j: LL = cl*xl, M = ch*xl + cl*xh, HH = ch*xh, so
+//            sum_d x_d c_jd = LL + 256 M + 65536 HH exactly (int32 partials, int64 combine);
+//            argmin_j |c_j|^2 - 2 sum_d x_d c_jd, ties -> lowest j (SPEC.md §4).
+//   update:  sums[j][byte-plane] = onehot[j][px] * X[px][byte-plane] on v_mfma_i32_16x16x64_i8;
+//            one spare byte-plane is all ones and yields the counts. Accumulators live in
+//            registers for the whole workgroup; nothing but the tile load touches HBM.
+// The one-hot digit is 0x80 (= -128) to save a shift; it is divided out exactly at the end.
+// D = a * b + c with a 64-bit accumulator in ONE instruction. hipcc strength-reduces the C expression
+// into sign extensions, 64-bit shifts and borrow chains (~10 instructions); the count is what costs here.
+__device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
+    long long d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
+    return d;
+}
+
+constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
+                                          // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
+constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 46 KB LDS, 3 workgroups / CU
+constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 120 KB LDS, 1 workgroup / CU
+
+#ifndef GCS_KP_WAVES
+#define GCS_KP_WAVES 3
+#endif
+// DSTEPS = assign K-steps (16 planes = 32 byte-features each); LDS holds ROWS = 16*DSTEPS plane rows (>= D + 1:
+// the spare row D is the count row); the update has NT = 2*DSTEPS N-tiles (8 planes = 16 byte-planes each).
+// NST = 16-byte staging chunks per thread >= ceil(tile_bytes / 4096); surplus chunks re-copy the tile's last chunk.
+template <int KT, int NST, int DSTEPS>
+__global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
+                                     : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
+    const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
+    int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
+    // compact coarse levels of one tile: at most (D - D_0) * 128 bytes with D - D_0 <= D / 2 ... all of D when the
+    // bank has a single scale per level pair; sized for the worst case of the bucket
+    constexpr int KP_COARSE = DSTEPS == KP_DSTEPS_NARROW ? 40 * 128 : 104 * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_coarse[KP_COARSE];
+    __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
+    __shared__ long long s_const[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, part = blockIdx.x;
+    const int D = lo.D;
+    const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
+    const int ntiles = lo.ntiles;
+    const unsigned char *fb = feats + (size_t)b * ntiles * lo.tile_bytes;   // this image's tiles, each one contiguous run
+
+    // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16 in PHYSICAL
+    //      plane order, stored offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D.
+    uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
+    for (int i = tid; i < 8 * KT * KP_ROWS; i += KP_TP) {
+        const int j = i / KP_ROWS, r = i % KP_ROWS;
+        cs[i] = (j < K && r < D) ? (uint16_t)(cset[j * D + gcs_logical_of_plane(lo, r)] ^ 0x8080u) : (uint16_t)0;
+    }
+    __syncthreads();
+    // ---- per-cluster key base (exact int64): 16 * (|c|^2 - 2*(offset terms of the -128 digits)) + j.
+    //      key_j = base_j - 32 R0 - 8192 R1 - 2^21 R2 = 16 * score_j + j, so ONE 64-bit minimum yields the
+    //      best score and the lowest index on ties. 16 lanes per cluster, folded with lane shuffles.
+    {
+      for (int j = tid >> 4; j < 16; j += KP_TP / 16) {
+        const int sub = tid & 15;
+        long long nrm = 0, scl = 0, sch = 0;
+        if (j < K)
+            for (int d = sub; d < D; d += 16) {
+                const long long c = cs[j * KP_ROWS + d] ^ 0x8080u;
+                nrm += c * c;
+                scl += c & 255;
+                sch += c >> 8;
+            }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            nrm += __shfl_xor(nrm, m);
+            scl += __shfl_xor(scl, m);
+            sch += __shfl_xor(sch, m);
+        }
+        if (sub == 0) {
+            const long long q = 16384LL * D;
+            const long long g = (128 * scl - q) + 256 * (128 * (sch + scl) - 2 * q) + 65536 * (128 * sch - q);
+            s_const[j] = j < K ? 16 * (nrm - 2 * g) + j : (1LL << 62) + j;
+        }
+      }
+    }
+    // ---- assign A fragments: row r = 4*jj + pat of tile mt (cluster j = 8*mt + jj);
+    //      k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2, byte t&1): the 8 planes of a fragment are one
+    //      16-byte scratch read. Per plane (u16 w = digits cl | ch << 8) the pattern bytes (byte 0, byte 1) are
+    //      LL = (cl, 0) = w & 0x00ff, M = (ch, cl) = bytes swapped, HH = (0, ch) = w & 0xff00, row 3 = 0.
+    v4i apat[KT][KP_DSTEPS];
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const int jj = r >> 2, pat = r & 3;
+        const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
+        const unsigned sel = pat == 1 ? 0x02030001u : 0x03020100u;
+#pragma unroll
+        for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KP_DSTEPS; ++kk) {
+                const v4i w = *reinterpret_cast<const v4i *>(&cs[(8 * mt + jj) * KP_ROWS + 16 * kk + 8 * h]);
+                v4i f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = (int)(__builtin_amdgcn_perm(0u, (unsigned)w[e], sel) & msk);
+                apat[mt][kk] = f;
+            }
+    }
+    __syncthreads();                                   // scratch reads done: the tile buffer is free again
+    // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
+    if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
+    v4i accu[KP_NT];
+#pragma unroll
+    for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
+
+    // ---- staging: the tile is ONE contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
+    //      ci = tid + 256*i is 16 bytes at byte 16*ci: level-0 chunks (the first 32*D_0) go to plane row ci>>5,
+    //      pixels 8*(ci&31).. ; the rest is the compact coarse levels and goes to s_coarse untouched.
+    //      Loads and LDS writes are UNCONDITIONAL: a per-chunk guard makes hipcc branch around every
+    //      load / write with exec masking and drain vmcnt(0) before each write. Chunks beyond the tile
+    //      are clamped to its last chunk: they re-read and re-write it with its own data.
+    const int n0 = 32 * lo.DL[0];                      // level-0 chunks
+    const int nchunk = lo.tile_bytes >> 4;
+    v4i st[NST];
+    int sdst[NST], ssrc[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int ci = min(tid + KP_TP * i, nchunk - 1);
+        ssrc[i] = ci;
+        sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
+                          : (int)(size_t)&s_coarse[(ci - n0) * 16];
+    }
+    auto stage_load = [&](int tile) {
+        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) st[i] = src[ssrc[i]];
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            *reinterpret_cast<__attribute__((address_space(3))) v4i *>(sdst[i]) = st[i];
+    };
+    // Coarse levels: every group of 8 consecutive pixels of a plane row (one row of one 8x8 block) is the
+    // replication of 8 >> L level-L pixels of the compact copy (SPEC.md §3: feat[y][x] = g_L[y >> L][x >> L]).
+    auto expand_coarse = [&]() {
+        for (int L = 1; L < lo.n_levels; ++L) {
+            const int side = 8 >> L;                              // level-L pixels per block side
+            const unsigned char *srcL = s_coarse + (lo.off[L] - lo.off[1]);
+            const int items = lo.DL[L] * 32;                      // (plane, block in tile, fine row)
+            for (int it = tid; it < items; it += KP_TP) {
+                const int rr = it >> 5, grp = it & 31;
+                const int blkq = grp >> 3, iy = grp & 7;
+                const unsigned char *s = srcL + (((rr * 4 + blkq) * side + (iy >> L)) * side) * 2;
+                v4i o;
+                if (L == 1) {
+                    const v2i v = *reinterpret_cast<const v2i *>(s);          // 4 pixels
+                    o[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x01000100u);
+                    o[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x03020302u);
+                    o[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x01000100u);
+                    o[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x03020302u);
+                } else if (L == 2) {
+                    const unsigned v = *reinterpret_cast<const unsigned *>(s);  // 2 pixels
+                    o[0] = o[1] = (int)__builtin_amdgcn_perm(0u, v, 0x01000100u);
+                    o[2] = o[3] = (int)__builtin_amdgcn_perm(0u, v, 0x03020302u);
+                } else {
+                    const unsigned v = *reinterpret_cast<const uint16_t *>(s);  // 1 pixel
+                    o[0] = o[1] = o[2] = o[3] = (int)(v | (v << 16));
+                }
+                *reinterpret_cast<v4i *>(&s_tile[(lo.row0[L] + rr) * KP_PITCH + (blkq * 64 + iy * 8) * 2]) = o;
+            }
+        }
+    };
+
+    const int un = lane & 15, ug = lane >> 4;             // update operand coordinates
+    const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
+    const unsigned eqr = (unsigned)un * 0x01010101u;
+    const int cnt_bp = 2 * D;
+
+    // Sweep order: workgroup `part` takes logical tiles part, part+parts, ...; on odd passes the physical
+    // order is reversed (boustrophedon), so a pass starts on the tiles the previous pass read last, i.e. on
+    // what is still in the 256 MiB Infinity Cache.
+    auto phys = [&](int lt) { return reverse ? ntiles - 1 - lt : lt; };
+    int ltile = part;
+    if (ltile < ntiles) stage_load(phys(ltile));
+    for (; ltile < ntiles; ltile += parts) {
+        const int tile = phys(ltile);
+        stage_write();
+        __syncthreads();
+        // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
+        // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
+        __builtin_amdgcn_s_setprio(3);
+        if (ltile + parts < ntiles) stage_load(phys(ltile + parts));   // in flight during the MFMAs
+        __builtin_amdgcn_s_setprio(0);
+        if (lo.n_levels > 1) {
+            expand_coarse();
+            __syncthreads();
+        }
+
+        // this wave's block (one 8x8 block per wave): which pixels exist and vote
+        const int blk = __builtin_amdgcn_readfirstlane(4 * tile + wave);
+        const int by = blk / lo.bx_n, bx = blk - by * lo.bx_n;
+        // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int n = lane & 31, h = lane >> 5;
+            const int pl = wave * 64 + sub * 32 + n;
+            v16i acc[KT];
+#pragma unroll
+            for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][e] = 0;
+            // B fragments by hardware transpose: per 16-lane group ds_read_b64_tr_b16 reads a block of
+            // 4 rows (planes) x 16 columns (pixels) of 16-bit elements and gives lane i column i, i.e.
+            // the four planes of ITS pixel (cdna guide T10). Lane 4q+p of the group supplies the address
+            // of row q, columns 4p..4p+3. Two reads = 8 planes = the 16-byte fragment of one K-step.
+            // (Replaces 8 ds_read_u16 + 4 pack ops per K-step.) One asm statement: loads + their wait.
+            v4i bfr[KP_DSTEPS];
+            {
+                const int i16 = lane & 15, pxblk = (lane >> 4) & 1;
+                const unsigned addr = (unsigned)(size_t)&s_tile[(8 * h + (i16 >> 2)) * KP_PITCH +
+                                                                (wave * 64 + sub * 32 + 16 * pxblk + 4 * (i16 & 3)) * 2];
+                v2i fa[KP_DSTEPS], fbv[KP_DSTEPS];
+#pragma unroll
+                for (int kk = 0; kk < KP_DSTEPS; ++kk)       // the DS offset field holds 16 bits: K-step base in the VGPR
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+                                 "ds_read_b64_tr_b16 %1, %2 offset:%c3"
+                                 : "=&v"(fa[kk]), "=&v"(fbv[kk])
+                                 : "v"(addr + kk * 16 * KP_PITCH), "i"(4 * KP_PITCH)
+                                 : "memory");
+                // hipcc does not count asm loads: one explicit wait, then tie every destination register to it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int kk = 0; kk < KP_DSTEPS; ++kk) {
+                    asm volatile("" : "+v"(fa[kk]), "+v"(fbv[kk]));
+                    bfr[kk] = v4i{fa[kk][0], fa[kk][1], fbv[kk][0], fbv[kk][1]};
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KP_DSTEPS; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < KT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat[mt][kk], bfr[kk], acc[mt], 0, 0, 0);
+            // key = 16*score + j via v_mad_i64_i32 (3 instructions per cluster instead of ~25 of sign
+            // extension / 64-bit shift / borrow arithmetic): U = R0 + 256 R1 fits int32 (|U| < 2^30).
+            long long best = 0x7fffffffffffffffLL;
+#pragma unroll
+            for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int u = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g];
+                    long long key = mad_i64_i32(u, -32, s_const[8 * mt + 2 * g + h]);   // base: LDS broadcast read
+                    key = mad_i64_i32(acc[mt][4 * g + 2], -2097152, key);
+                    best = key < best ? key : best;
+                }
+            // partner half's key by v_permlane32_swap (VALU; no LDS round trip like ds_bpermute)
+            const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
+            // after swap(x, x): element 1 holds the upper half's x in lanes 0-31, element 0 the lower half's x in lanes 32-63
+            const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1[0] : s1[1];
+            const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
+            const int bj = (int)((pb < best ? pb : best) & 15);
+            if (h == 0) {
+                const int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7);
+                const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
+                s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
+                labels[((size_t)b * ntiles + tile) * KP_TP + pl] = (uint8_t)bj;
+            }
+        }
+        // -------- update: one-hot MFMA over this wave's 64 pixels
+        {
+            const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
+            v4i oh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned x = (unsigned)lw[i] ^ eqr;                    // byte == 0 <=> label == un
+                const unsigned y = (x | 0x80808080u) - 0x01010101u;        // top bit clear <=> byte == 0
+                oh[i] = (int)(~y & 0x80808080u);                            // digit -128 where label == un
+            }
+#pragma unroll
+            for (int nt = 0; nt < KP_NT; ++nt) {
+                const int d = 8 * nt + (un >> 1);
+                const v4i *src = reinterpret_cast<const v4i *>(&s_tile[d * KP_PITCH + (wave * 64 + 16 * ug) * 2]);
+                const v4i w0 = src[0], w1 = src[1];
+                v4i bx_;
+                bx_[0] = (int)__builtin_amdgcn_perm((unsigned)w0[1], (unsigned)w0[0], usel);
+                bx_[1] = (int)__builtin_amdgcn_perm((unsigned)w0[3], (unsigned)w0[2], usel);
+                bx_[2] = (int)__builtin_amdgcn_perm((unsigned)w1[1], (unsigned)w1[0], usel);
+                bx_[3] = (int)__builtin_amdgcn_perm((unsigned)w1[3], (unsigned)w1[2], usel);
+                accu[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row: every wave
+    //      parks its registers in its own slice of the tile buffer (no zero-fill, no atomics), one barrier.
+    constexpr int RW = KP_NT * 16;                            // byte-planes per cluster row
+    int *red = reinterpret_cast<int *>(s_tile);               // [KP_TP / 64 waves][16][RW]
+    static_assert((KP_TP / 64) * 16 * RW * 4 <= KP_ROWS * KP_PITCH, "fold buffer exceeds the tile buffer");
+#pragma unroll
+    for (int nt = 0; nt < KP_NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[nt][e];
+    __syncthreads();
+    const int D1 = D + 1;
+    auto folded = [&](int j, int bp) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < KP_TP / 64; ++w) s += red[(w * 16 + j) * RW + bp];
+        return -(long long)s / 128;                           // the one-hot digit is -128
+    };
+    for (int i = tid; i < K * D1; i += KP_TP) {
+        const int j = i / D1, e = i % D1;                     // e = LOGICAL feature (or D = the count)
+        const long long nj = folded(j, cnt_bp);
+        long long out = nj;
+        if (e < D) {
+            const int pe = gcs_plane_of_logical(lo, e);
+            out = (folded(j, 2 * pe) + 128 * nj) + 256 * (folded(j, 2 * pe + 1) + 128 * nj);
+        }
+        partials[partial_index(per_image, b, part, parts, i, K * D1)] = (uint64_t)out;
+    }
+}
+
+static size_t assign_lds_bytes(int D, int k, int R) {
+    size_t a = ((size_t)D * k * 2 * 4 + 15) & ~(size_t)15;
+    size_t c = ((size_t)k * 8 + 15) & ~(size_t)15;
+    return a + c + (size_t)k * (D + 1) * R * 4;
+}
+
+template <int K>
+static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, const GcsLayout &lo, int n_sets,
+                         int row_lo, int row_hi, uint8_t *labels, uint64_t *partials, hipStream_t stream) {
+    const int D = lo.D;
+    const int parts = (int)gcs_kmeans_parts_per_image(B, lo.H, lo.W);
+    int R = 32;
+    while (R > 1 && assign_lds_bytes(D, K, R) > 120 * 1024) R >>= 1;
+    const size_t lds = assign_lds_bytes(D, K, R);
+    if (lds > 160 * 1024) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k*D too large for LDS");
+    // raise the dynamic-LDS cap: per device and cheap, so set on every launch (no process-wide cache to race on)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return gcs_hip_fail(e, "hipFuncSetAttribute(assign)");
+    hipLaunchKernelGGL(kmeans_assign_kernel<K>, dim3(parts, B), dim3(256), lds, stream,
+                       reinterpret_cast<const unsigned char *>(feats), cent, lo, n_sets == B ? 1 : 0, parts, R, row_lo,
+                       row_hi, labels, partials);
+    GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
+    return GCS_OK;
+}
+
+extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
+                                            int n_scales, int n_orient, int k, int n_sets, int row_lo, int row_hi,
+                                            int reverse, uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
+    if (!feats || !cent || !labels || !partials)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer");
+    LAYOUT_OR_FAIL(lo, "gcs_kmeans_assign_accumulate");
+    if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: need 0 <= row_lo < row_hi <= H");
+    if (B > 65535) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: B too large for one launch");
+    if (k < 1 || k > GCS_K_MAX) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
+    if (n_sets != 1 && n_sets != B)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
+    const int D = lo.D;
+    if (D < 16 * KP_DSTEPS_WIDE) { // matrix-core pass (every BASELINE bank: 4x6 -> D = 72, 8x8 -> D = 192)
+        const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
+#define GCS_KP_LAUNCH(KT_, NST_, DS_)                                                                             \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_>), dim3(parts, B), dim3(KP_TP), 0, stream,         \
+                       reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,   \
+                       reverse ? 1 : 0, row_lo, row_hi, labels, partials)
+        const int nst = (lo.tile_bytes / 16 + KP_TP - 1) / KP_TP;     // staging chunks per thread
+        if (D < 16 * KP_DSTEPS_NARROW) {
+            if (k <= 8) {
+                if (nst <= 3) { GCS_KP_LAUNCH(1, 3, KP_DSTEPS_NARROW); }
+                else if (nst <= 6) { GCS_KP_LAUNCH(1, 6, KP_DSTEPS_NARROW); }
+                else if (nst <= 9) { GCS_KP_LAUNCH(1, 9, KP_DSTEPS_NARROW); }
+                else { GCS_KP_LAUNCH(1, 10, KP_DSTEPS_NARROW); }
+            } else {
+                if (nst <= 6) { GCS_KP_LAUNCH(2, 6, KP_DSTEPS_NARROW); }
+                else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
+            }
+        } else if (k <= 8) {
+            if (nst <= 10) { GCS_KP_LAUNCH(1, 10, KP_DSTEPS_WIDE); }
+            else if (nst <= 18) { GCS_KP_LAUNCH(1, 18, KP_DSTEPS_WIDE); }
+            else { GCS_KP_LAUNCH(1, 26, KP_DSTEPS_WIDE); }
+        } else {
+            if (nst <= 10) { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_WIDE); }
+            else if (nst <= 18) { GCS_KP_LAUNCH(2, 18, KP_DSTEPS_WIDE); }
+            else { GCS_KP_LAUNCH(2, 26, KP_DSTEPS_WIDE); }
+        }
+#undef GCS_KP_LAUNCH
+        GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
+        return GCS_OK;
+    }
+    switch (k) { // generic VALU pass for wider feature vectors
+#define GCS_CASE(KK) \
+    case KK:         \
+        return launch_assign<KK>(feats, cent, B, lo, n_sets, row_lo, row_hi, labels, partials, stream);
+        GCS_CASE(1) GCS_CASE(2) GCS_CASE(3) GCS_CASE(4) GCS_CASE(5) GCS_CASE(6) GCS_CASE(7) GCS_CASE(8)
+        GCS_CASE(9) GCS_CASE(10) GCS_CASE(11) GCS_CASE(12) GCS_CASE(13) GCS_CASE(14) GCS_CASE(15) GCS_CASE(16)
+#undef GCS_CASE
+    }
+    return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
+}
+
+// sums[set][e] = sum of the set's partial values of element e (one contiguous run, see partial_index). Integer
+// sums: any order gives the same bits. One wave per element: coalesced reads, shuffle fold.
+// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in between): the wave
+// also folds the count element of its cluster, so no second kernel and no cross-block dependency is needed.
+template <bool FIN>
+__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
+                                                            int rows_per_set, int row_len, int D1,
+                                                            long long *__restrict__ sums,
+                                                            uint16_t *__restrict__ cent) {
+    const int set = blockIdx.y, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= row_len) return;                                  // whole waves leave; no barrier below
+    const int j = e / D1, d = e - j * D1;
+    const uint64_t *p = partials + ((size_t)set * row_len + e) * rows_per_set;
+    const uint64_t *pc = partials + ((size_t)set * row_len + j * D1 + (D1 - 1)) * rows_per_set;
+    uint64_t s = 0, c = 0;
+    for (int r = lane; r < rows_per_set; r += 64) {
+        s += p[r];
+        if (FIN) c += pc[r];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s += __shfl_xor(s, m);
+        if (FIN) c += __shfl_xor(c, m);
+    }
+    if (lane == 0) {
+        if (sums) sums[(size_t)set * row_len + e] = (long long)s;
+        if (FIN && d < D1 - 1 && c > 0)
+            cent[((size_t)set * (row_len / D1) + j) * (D1 - 1) + d] = (uint16_t)((2 * s + c) / (2 * c));
+    }
+}
+
+static int reduce_args_ok(const void *partials, int B, int H, int W, int D, int k, int n_sets, const char *who) {
+    if (!partials) return gcs_fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX) return gcs_fail(GCS_EINVAL, who);
+    if (n_sets != 1 && n_sets != B) return gcs_fail(GCS_EINVAL, "gcs_kmeans_reduce: n_sets must be 1 or B");
+    return GCS_OK;
+}
+
+extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
+                                 int64_t *sums, gcs_stream_t stream) {
+    if (!sums) return gcs_fail(GCS_EINVAL, "gcs_kmeans_reduce: NULL pointer");
+    if (int rc = reduce_args_ok(partials, B, H, W, D, k, n_sets, "gcs_kmeans_reduce: bad shape")) return rc;
+    const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
+    const int row_len = k * (D + 1);
+    const int rows_per_set = n_sets == B ? parts : B * parts;
+    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
+                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
+    GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
+    return GCS_OK;
+}
+
+extern "C" int gcs_kmeans_reduce_finalize(const uint64_t *partials, int B, int H, int W, int D, int k, int n_sets,
+                                          int64_t *sums, uint16_t *cent, gcs_stream_t stream) {
+    if (!cent) return gcs_fail(GCS_EINVAL, "gcs_kmeans_reduce_finalize: NULL pointer");
+    if (int rc = reduce_args_ok(partials, B, H, W, D, k, n_sets, "gcs_kmeans_reduce_finalize: bad shape")) return rc;
+    const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
+    const int row_len = k * (D + 1);
+    const int rows_per_set = n_sets == B ? parts : B * parts;
+    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
+                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_reduce_finalize");
+    return GCS_OK;
+}
+
+__global__ void kmeans_finalize_kernel(const long long *__restrict__ sums, int n, int k, int D,
+                                       uint16_t *__restrict__ cent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = i % D, j = (i / D) % k, set = i / (D * k);
+    const long long *row = sums + ((size_t)set * k + j) * (D + 1);
+    const long long cnt = row[D];
+    if (cnt > 0) cent[i] = (uint16_t)((2 * row[d] + cnt) / (2 * cnt));
+}
+
+extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D, uint16_t *cent,
+                                   gcs_stream_t stream) {
+    if (!sums || !cent) return gcs_fail(GCS_EINVAL, "gcs_kmeans_finalize: NULL pointer");
+    if (n_sets <= 0 || D <= 0 || k < 1 || k > GCS_K_MAX) return gcs_fail(GCS_EINVAL, "gcs_kmeans_finalize: bad shape");
+    const int n = n_sets * k * D;
+    hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const long long *>(sums), n, k, D, cent);
+    GCS_CHECK_LAUNCH("gcs_kmeans_finalize");
+    return GCS_OK;
+}
+
+// ----------------------------------------------------------------------------- label slab -> raster
+// Block = 64 x 4 threads: four image rows per block; a thread converts 4 labels of one row (half a block row: one
+// aligned dword of the slab) per step of 64 dwords.
+template <typename OUT>
+__global__ __launch_bounds__(256) void labels_raster_kernel(const uint8_t *__restrict__ labels, int H, int W, int bx_n,
+                                                            int ntiles, int rows, OUT *__restrict__ out) {
+    const int byr = blockIdx.x * 4 + threadIdx.y;     // b*H + y
+    if (byr >= rows) return;
+    const int b = byr / H, y = byr - b * H;
+    const uint8_t *img = labels + (size_t)b * ntiles * KP_TP;
+    OUT *dst = out + (size_t)byr * W;
+    for (int x4 = threadIdx.x; 4 * x4 < W; x4 += 64) {
+        const int blk = (y >> 3) * bx_n + (x4 >> 1);
+        const unsigned v = *reinterpret_cast<const unsigned *>(img + (size_t)(blk >> 2) * KP_TP + (blk & 3) * 64 +
+                                                               (y & 7) * 8 + (x4 & 1) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * x4 + e < W) dst[4 * x4 + e] = (OUT)((v >> (8 * e)) & 255u);
+    }
+}
+
+template <typename OUT>
+static int labels_raster(const uint8_t *labels, int B, int H, int W, OUT *out, hipStream_t stream, const char *who) {
+    if (!labels || !out) return gcs_fail(GCS_EINVAL, who);
+    GcsLayout lo;
+    if (B <= 0 || (long long)B * H > 0x7fffffffLL || !gcs_make_layout(H, W, 1, 1, &lo)) return gcs_fail(GCS_EINVAL, who);
+    const int rows = B * H;
+    hipLaunchKernelGGL(labels_raster_kernel<OUT>, dim3((rows + 3) / 4), dim3(64, 4), 0, stream, labels, H, W, lo.bx_n,
+                       lo.ntiles, rows, out);
+    GCS_CHECK_LAUNCH(who);
+    return GCS_OK;
+}
+
+extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream) {
+    return labels_raster<int32_t>(labels, B, H, W, out, stream, "gcs_labels_widen: bad argument");
+}
+extern "C" int gcs_labels_raster_u8(const uint8_t *labels, int B, int H, int W, uint8_t *out, gcs_stream_t stream) {
+    return labels_raster<uint8_t>(labels, B, H, W, out, stream, "gcs_labels_raster_u8: bad argument");
+}

@@ -1,0 +1,273 @@
+// scoring.hip — evaluation-side kernels of libgcs.so (gfx950): boundary recall / precision counts
+// (/root/reference/BSD_metrics/metrics.py:58-96), region tables (metrics.py:102-201) and connected regions (SPEC.md §7).
+// Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
+#include "common.h"
+
+// ======================================================================= boundary scoring (§8f-1)
+// Integer restatement of /root/reference/BSD_metrics/metrics.py:25-51,58-96 for ONE image:
+//   bd(M)   = thick boundaries of an integer map M: max != min over the 3x3 cross (find_boundaries
+//             defaults; reflect border == clamped indices for max/min filters)
+//   dil5(b) = 5x5 binary dilation (dilation(., rectangle(5,5)); same border argument)
+// counts[0] = sum bd(L);  per annotator a: counts[1+3a] = sum dil5(bd(L)) & bd(T_a)   (recall numerator)
+//                                           counts[2+3a] = sum bd(T_a)                 (recall denominator)
+//                                           counts[3+3a] = sum bd(L) & dil5(bd(T_a))   (precision numerator)
+// The float divisions and the per-annotator mean stay on the host, in the reference's order.
+template <typename T>
+__device__ __forceinline__ bool thick_boundary(const T *m, int H, int W, int y, int x) {
+    const T c = m[(size_t)y * W + x];
+    const T u = m[(size_t)max(y - 1, 0) * W + x], d = m[(size_t)min(y + 1, H - 1) * W + x];
+    const T l = m[(size_t)y * W + max(x - 1, 0)], r = m[(size_t)y * W + min(x + 1, W - 1)];
+    return u != c || d != c || l != c || r != c;   // max != min over {c,u,d,l,r}
+}
+
+// maps: plane 0 = boundaries of the label map, planes 1..A = boundaries of the annotator maps
+__global__ void boundary_maps_kernel(const int32_t *__restrict__ labels, const uint16_t *__restrict__ truth, int A,
+                                     int H, int W, uint8_t *__restrict__ maps) {
+    const int n = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (A + 1) * n; i += gridDim.x * blockDim.x) {
+        const int a = i / n, p = i % n, y = p / W, x = p % W;
+        maps[i] = a == 0 ? thick_boundary(labels, H, W, y, x)
+                         : thick_boundary(truth + (size_t)(a - 1) * n, H, W, y, x);
+    }
+}
+
+__device__ __forceinline__ bool dilated5(const uint8_t *b, int H, int W, int y, int x) {
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if (xx >= 0 && xx < W && b[(size_t)yy * W + xx]) return true;
+        }
+    }
+    return false;
+}
+
+__global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, int A, int H, int W,
+                                       unsigned long long *__restrict__ counts) {
+    const int n = H * W;
+    const int a = blockIdx.y;                         // 0: label-only count, 1..A: annotator a-1
+    unsigned c0 = 0, c1 = 0, c2 = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p % W;
+        const bool bl = maps[p];
+        if (a == 0) {
+            c0 += bl;
+        } else {
+            const uint8_t *tb = maps + (size_t)a * n;
+            const bool bt = tb[p];
+            c0 += bt && dilated5(maps, H, W, y, x);  // recall numerator
+            c1 += bt;                                  // recall denominator
+            c2 += bl && dilated5(tb, H, W, y, x);    // precision numerator
+        }
+    }
+    // wave reduction, one atomic per wave (integers: order-independent)
+    for (int m = 32; m >= 1; m >>= 1) {
+        c0 += __shfl_xor(c0, m);
+        c1 += __shfl_xor(c1, m);
+        c2 += __shfl_xor(c2, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a == 0) {
+            atomicAdd(&counts[0], (unsigned long long)c0);
+        } else {
+            atomicAdd(&counts[1 + 3 * (a - 1)], (unsigned long long)c0);
+            atomicAdd(&counts[2 + 3 * (a - 1)], (unsigned long long)c1);
+            atomicAdd(&counts[3 + 3 * (a - 1)], (unsigned long long)c2);
+        }
+    }
+}
+
+extern "C" size_t gcs_boundary_scratch_bytes(int A, int H, int W) {
+    if (A <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)(A + 1) * H * W;
+}
+
+extern "C" int gcs_boundary_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, void *scratch,
+                                   uint64_t *counts, gcs_stream_t stream) {
+    if (!labels || !truth || !scratch || !counts) return gcs_fail(GCS_EINVAL, "gcs_boundary_counts: NULL pointer");
+    if (A <= 0 || A > 65535 || H <= 0 || W <= 0 || (long long)H * W * (A + 1) > 0x7fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_boundary_counts: bad shape");
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(1 + 3 * A) * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return gcs_hip_fail(e, "gcs_boundary_counts(memset)");
+    uint8_t *maps = static_cast<uint8_t *>(scratch);
+    const int n = H * W;
+    hipLaunchKernelGGL(boundary_maps_kernel, dim3(min(2048, ((A + 1) * n + 255) / 256)), dim3(256), 0, stream, labels,
+                       truth, A, H, W, maps);
+    GCS_CHECK_LAUNCH("gcs_boundary_counts(maps)");
+    hipLaunchKernelGGL(boundary_counts_kernel, dim3(min(256, (n + 255) / 256), A + 1), dim3(256), 0, stream, maps, A, H,
+                       W, reinterpret_cast<unsigned long long *>(counts));
+    GCS_CHECK_LAUNCH("gcs_boundary_counts");
+    return GCS_OK;
+}
+
+// ================================================================== connected regions (§8f-4)
+// SPEC.md §7: 4-connected components of equal labels, renumbered 0,1,2,... in raster order of each
+// component's first pixel (so "Regions" = max+1 at /root/reference/BSD_metrics/metrics.py:51 counts
+// connected regions, as it does for the SLIC output the slot holds today). Lock-free union-find:
+// parents only ever decrease (atomicMin), a root is the smallest pixel index of its component, and a
+// failed link (someone re-parented the node meanwhile) retries from the displaced parent, so no
+// equivalence is lost even when a find reads a stale pointer.
+__device__ __forceinline__ int cc_find(const int *parent, int x) {
+    for (;;) {
+        const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
+
+__device__ __forceinline__ void cc_unite(int *parent, int a, int b) {
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // link the larger root under the smaller
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;                                          // a was re-parented meanwhile: merge that chain too
+    }
+}
+
+__global__ void cc_union_kernel(const int32_t *__restrict__ labels, int H, int W, int *__restrict__ parent) {
+    const int P = H * W;
+    const int32_t *lab = labels + (size_t)blockIdx.y * P;
+    int *par = parent + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int y = p / W, x = p % W;
+        const int32_t l = lab[p];
+        if (x + 1 < W && lab[p + 1] == l) cc_unite(par, p, p + 1);
+        if (y + 1 < H && lab[p + W] == l) cc_unite(par, p, p + W);
+    }
+}
+
+__global__ void cc_local_init_kernel(int H, int W, int *__restrict__ parent) {
+    const int P = H * W;
+    int *par = parent + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) par[p] = p;
+}
+
+// one workgroup per image: flatten, count roots per contiguous chunk, scan, hand out ids in raster order
+__global__ __launch_bounds__(1024) void cc_rank_kernel(int H, int W, int *__restrict__ parent, int *__restrict__ rootid) {
+    __shared__ int s_cnt[1024];
+    const int P = H * W;
+    int *par = parent + (size_t)blockIdx.x * P;
+    int *rid = rootid + (size_t)blockIdx.x * P;
+    const int tid = threadIdx.x;
+    const int chunk = (P + 1023) / 1024;
+    const int lo = min(P, tid * chunk), hi = min(P, lo + chunk);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += par[p] == p;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int id = s_cnt[tid] - cnt;                           // exclusive prefix = first id of this chunk
+    for (int p = lo; p < hi; ++p)
+        if (par[p] == p) rid[p] = id++;
+}
+
+__global__ void cc_relabel_kernel(int H, int W, const int *__restrict__ parent, const int *__restrict__ rootid,
+                                  int32_t *__restrict__ out) {
+    const int P = H * W;
+    const int *par = parent + (size_t)blockIdx.y * P;
+    const int *rid = rootid + (size_t)blockIdx.y * P;
+    int32_t *o = out + (size_t)blockIdx.y * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int r = par[p];
+        while (par[r] != r) r = par[r];                  // the union kernel has finished: plain loads are current
+        o[p] = rid[r];
+    }
+}
+
+extern "C" size_t gcs_connected_scratch_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)2 * B * H * W * sizeof(int32_t);
+}
+
+extern "C" int gcs_connected_regions(const int32_t *labels, int B, int H, int W, void *scratch, int32_t *out,
+                                     gcs_stream_t stream) {
+    if (!labels || !scratch || !out) return gcs_fail(GCS_EINVAL, "gcs_connected_regions: NULL pointer");
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_connected_regions: bad shape");
+    const int P = H * W;
+    int *parent = static_cast<int *>(scratch);
+    int *rootid = parent + (size_t)B * P;
+    const dim3 grid(min(1024, (P + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(cc_local_init_kernel, grid, block, 0, stream, H, W, parent);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(init)");
+    hipLaunchKernelGGL(cc_union_kernel, grid, block, 0, stream, labels, H, W, parent);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(union)");
+    hipLaunchKernelGGL(cc_rank_kernel, dim3(B), dim3(1024), 0, stream, H, W, parent, rootid);
+    GCS_CHECK_LAUNCH("gcs_connected_regions(rank)");
+    hipLaunchKernelGGL(cc_relabel_kernel, grid, block, 0, stream, H, W, parent, rootid, out);
+    GCS_CHECK_LAUNCH("gcs_connected_regions");
+    return GCS_OK;
+}
+
+// ======================================================================= region tables (§8f-2)
+// Integer part of /root/reference/BSD_metrics/metrics.py:102-146 (label x annotator contingency table and region
+// areas) and :160-181 (4-neighbour perimeter: image-border pixels, or pixels with a different 4-neighbour). One
+// thread per pixel; workgroup-private tables in LDS when they fit (k-means label maps: a few clusters, every
+// atomic on a handful of addresses), global atomics otherwise (connected regions: thousands of sparse rows).
+__global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__restrict__ labels,
+                                                            const uint16_t *__restrict__ truth, int A, int H, int W,
+                                                            int n_seg, int stride, int use_lds,
+                                                            unsigned *__restrict__ hist, unsigned *__restrict__ area,
+                                                            unsigned *__restrict__ perim) {
+    extern __shared__ unsigned s_tab[];                        // [A][n_seg][stride] hist | [n_seg] area | [n_seg] perim
+    const int n_hist = A * n_seg * stride, n_tab = n_hist + 2 * n_seg;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = 0u;
+        __syncthreads();
+    }
+    unsigned *t_hist = use_lds ? s_tab : hist, *t_area = use_lds ? s_tab + n_hist : area,
+             *t_perim = use_lds ? s_tab + n_hist + n_seg : perim;
+    const int P = H * W;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int l = labels[p];
+        if ((unsigned)l >= (unsigned)n_seg) continue;          // caller passes n_seg = max + 1; never index outside
+        const int y = p / W, x = p - y * W;
+        bool edge = y == 0 || y == H - 1 || x == 0 || x == W - 1;
+        if (!edge) edge = labels[p - W] != l || labels[p + W] != l || labels[p - 1] != l || labels[p + 1] != l;
+        atomicAdd(&t_area[l], 1u);
+        if (edge) atomicAdd(&t_perim[l], 1u);
+        for (int a = 0; a < A; ++a) {
+            const int t = truth[(size_t)a * P + p];
+            if (t < stride) atomicAdd(&t_hist[((size_t)a * n_seg + l) * stride + t], 1u);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_tab; i += blockDim.x) {
+            const unsigned v = s_tab[i];
+            if (v) atomicAdd(i < n_hist ? &hist[i] : i < n_hist + n_seg ? &area[i - n_hist] : &perim[i - n_hist - n_seg], v);
+        }
+    }
+}
+
+extern "C" int gcs_region_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, int n_segments,
+                                 int n_truth_labels, uint32_t *hist, uint32_t *area, uint32_t *perim,
+                                 gcs_stream_t stream) {
+    if (!labels || !truth || !hist || !area || !perim) return gcs_fail(GCS_EINVAL, "gcs_region_counts: NULL pointer");
+    if (A <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || n_segments <= 0 || n_truth_labels <= 0 ||
+        (long long)A * n_segments * n_truth_labels > 0x3fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_region_counts: bad shape");
+    const size_t n_hist = (size_t)A * n_segments * n_truth_labels;
+    hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)n_segments * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)n_segments * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return gcs_hip_fail(e, "gcs_region_counts(memset)");
+    const size_t lds = (n_hist + 2 * (size_t)n_segments) * sizeof(unsigned);
+    const int use_lds = lds <= 48 * 1024;
+    const int P = H * W;
+    const int blocks = use_lds ? min(256, (P + 1023) / 1024) : min(2048, (P + 255) / 256);
+    hipLaunchKernelGGL(region_counts_kernel, dim3(blocks), dim3(256), use_lds ? lds : 0, stream, labels, truth, A, H, W,
+                       n_segments, n_truth_labels, use_lds, hist, area, perim);
+    GCS_CHECK_LAUNCH("gcs_region_counts");
+    return GCS_OK;
+}
+

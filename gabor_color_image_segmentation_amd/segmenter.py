@@ -41,11 +41,12 @@ class HipOps:
         self.torch = torch
         self.device = torch.device(device)
         self.bank = bank
-        nf = bank.n_filters
-        packed = np.zeros(self.lib.gcs_bank_packed_bytes(nf), np.int8)
-        bias = np.zeros(self.lib.gcs_bank_bias_count(nf), np.int32)
+        ns, no = bank.n_scales, bank.n_orient
+        self._bk = (ns, no)                      # the bank as the C ABI describes it
+        packed = np.zeros(self.lib.gcs_bank_packed_bytes(ns, no), np.int8)
+        bias = np.zeros(self.lib.gcs_bank_bias_count(ns, no), np.int32)
         tapq = np.ascontiguousarray(bank.tapq, np.int16)
-        _lib.check(self.lib.gcs_bank_pack(tapq.ctypes.data, nf, bank.ksize, packed.ctypes.data,
+        _lib.check(self.lib.gcs_bank_pack(tapq.ctypes.data, ns, no, bank.ksize, packed.ctypes.data,
                                           bias.ctypes.data), "gcs_bank_pack")
         self.packed = torch.from_numpy(packed).to(self.device)
         self.bias = torch.from_numpy(bias).to(self.device)
@@ -56,7 +57,7 @@ class HipOps:
         return self.torch.empty(int(n), dtype=self.torch.uint8, device=self.device)
 
     def feature_slab(self, b, h, w):
-        return self.empty_bytes(self.lib.gcs_feature_slab_bytes(b, h, w, self.bank.n_features))
+        return self.empty_bytes(self.lib.gcs_feature_slab_bytes(b, h, w, *self._bk))
 
     def label_slab(self, b, h, w):
         return self.empty_bytes(self.lib.gcs_label_slab_bytes(b, h, w))
@@ -70,11 +71,11 @@ class HipOps:
     # ---- device entry points
     def gabor_features(self, imgs, feats):
         b, h, w, _ = imgs.shape
-        need = self.lib.gcs_gabor_workspace_bytes(b, h, w)
+        need = self.lib.gcs_gabor_workspace_bytes(b, h, w, self.bank.n_scales)
         if self._gabor_ws is None or self._gabor_ws.numel() < need:
             self._gabor_ws = self.empty_bytes(need)
         _lib.check(self.lib.gcs_gabor_features(imgs.data_ptr(), b, h, w, self.packed.data_ptr(),
-                                               self.bias.data_ptr(), self.bank.n_filters,
+                                               self.bias.data_ptr(), *self._bk,
                                                self.bank.shift, self._gabor_ws.data_ptr(),
                                                feats.data_ptr(), self._stream()),
                    "gcs_gabor_features")
@@ -82,18 +83,18 @@ class HipOps:
     def features_unpack(self, feats, b, h, w):
         d = self.bank.n_features
         out = self.torch.empty((b, d, h, w), dtype=self.torch.int16, device=self.device)
-        _lib.check(self.lib.gcs_features_unpack(feats.data_ptr(), b, h, w, d, out.data_ptr(),
+        _lib.check(self.lib.gcs_features_unpack(feats.data_ptr(), b, h, w, *self._bk, out.data_ptr(),
                                                 self._stream()), "gcs_features_unpack")
         return out
 
     def kmeans_init(self, feats, b, h, w, k, n_sets, cent):
-        _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
+        _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, *self._bk, k, n_sets,
                                             cent.data_ptr(), self._stream()), "gcs_kmeans_init")
 
     def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None, reverse=False):
         lo, hi = rows if rows is not None else (0, h)
         _lib.check(self.lib.gcs_kmeans_assign_accumulate(
-            feats.data_ptr(), cent.data_ptr(), b, h, w, self.bank.n_features, k, n_sets, lo, hi,
+            feats.data_ptr(), cent.data_ptr(), b, h, w, *self._bk, k, n_sets, lo, hi,
             1 if reverse else 0, labels.data_ptr(), partials.data_ptr(), self._stream()),
             "gcs_kmeans_assign_accumulate")
 
@@ -101,7 +102,7 @@ class HipOps:
         """byx: (n,3) int32 device tensor of (image, row, col); image < 0 -> zero row. -> (n,D) int16."""
         n = byx.shape[0]
         out = self.torch.empty((n, self.bank.n_features), dtype=self.torch.int16, device=self.device)
-        _lib.check(self.lib.gcs_features_gather(feats.data_ptr(), b, h, w, self.bank.n_features, n,
+        _lib.check(self.lib.gcs_features_gather(feats.data_ptr(), b, h, w, *self._bk, n,
                                                 byx.data_ptr(), out.data_ptr(), self._stream()),
                    "gcs_features_gather")
         return out
@@ -235,7 +236,7 @@ class Segmenter:
     def group_size(self, b, h, w, mode):
         if mode == "global":
             return b
-        per_image = self.ops.lib.gcs_feature_slab_bytes(1, h, w, self.bank.n_features) \
+        per_image = self.ops.lib.gcs_feature_slab_bytes(1, h, w, self.bank.n_scales, self.bank.n_orient) \
             if hasattr(self.ops, "lib") else 2 * self.bank.n_features * h * w
         return max(1, min(b, _SLAB_BUDGET // max(1, per_image)))
 

@@ -31,33 +31,35 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 10
-#define GCS_KSIZE_MAX 15 /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
-#define GCS_K_MAX 16     /* clusters */
+#define GCS_ABI_VERSION 11
+#define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
+#define GCS_K_MAX 16      /* clusters */
+#define GCS_SCALES_MAX 8  /* octave pyramid of at most 4 levels: scales 2L, 2L+1 run on level L (SPEC.md §2) */
 
 int gcs_abi_version(void);
 const char *gcs_last_error(void);
 
+/* The bank is described by (n_scales, n_orient): F = n_scales * n_orient filters, f = s * n_orient + o,
+ * D = 3F features per pixel, d = c * F + f (SPEC.md §2-§3). */
+
 /* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
 
-/* Filters are padded to a multiple of 8 (one 32-row MFMA tile = 8 filters x {re,im} x
- * {lo,hi} digits). Bytes of the packed A-operand image / number of int32 bias words. */
-size_t gcs_bank_packed_bytes(int n_filters);
-size_t gcs_bank_bias_count(int n_filters);
+/* Filters are packed level by level, each level padded to a multiple of 8 filters (one 32-row MFMA tile =
+ * 8 filters x {re,im} x {lo,hi} digits). Bytes of the packed A-operand image / number of int32 bias words. */
+size_t gcs_bank_packed_bytes(int n_scales, int n_orient);
+size_t gcs_bank_bias_count(int n_scales, int n_orient);
 
-/* Pack quantised taps tapq[F][2][ks][ks] (int16, SPEC.md §2) into the lane-linear int8
- * A-fragments of v_mfma_i32_32x32x32_i8 and the per-filter bias 128*sum(tapq_re)
- * (pixels are fed as img-128). Replaces nothing in the reference (bank absent). */
-int gcs_bank_pack(const int16_t *tapq, int n_filters, int ksize, int8_t *packed, int32_t *bias);
+/* Pack quantised taps tapq[F][2][ks][ks] (int16, SPEC.md §2) into the lane-linear int8 A-fragments of
+ * v_mfma_i32_32x32x32_i8 and the per-filter bias 128*sum(tapq_re) (pixels are fed as img-128).
+ * Replaces nothing in the reference (bank absent). */
+int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ksize, int8_t *packed, int32_t *bias);
 
-/* Feature slab geometry: tile-major [B][plane_stride/256][D][256 px] uint16, stored offset-binary
- * (x ^ 0x8080: both bytes are signed MFMA digits), rows of `pitch` = W rounded up to 8 pixels,
- * plane_stride = H*pitch rounded up to 256 pixels. The slab is opaque to callers;
- * gcs_features_unpack gives the canonical [B][D][H][W] uint16 layout. */
-size_t gcs_feature_pitch(int W);
-size_t gcs_feature_plane_stride(int H, int W);
-size_t gcs_feature_slab_bytes(int B, int H, int W, int D);
-size_t gcs_label_slab_bytes(int B, int H, int W); /* uint8 [B][plane_stride] */
+/* Feature slab: every pyramid level at its own resolution, tile-major (a tile = four 8x8-pixel blocks with
+ * their level-1..3 parents, one contiguous run; see csrc/common.h), uint16 stored offset-binary (x ^ 0x8080:
+ * both bytes are signed MFMA digits). Opaque to callers; gcs_features_unpack gives the canonical
+ * [B][D][H][W] uint16 tensor of SPEC.md §3. Label slab: uint8 in the same pixel order. */
+size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient);
+size_t gcs_label_slab_bytes(int B, int H, int W);
 /* uint64 partial sums written by one assign pass: B * parts * k * (D+1) values, one per k-means workgroup and
  * output element (element-major; opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */
 size_t gcs_kmeans_parts_per_image(int B, int H, int W);
@@ -65,29 +67,29 @@ size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 
 /* ---- device entry points ---------------------------------------------------------------- */
 
-/* Scratch for gcs_gabor_features: the reflect-padded planar (pixel-128) image. */
-size_t gcs_gabor_workspace_bytes(int B, int H, int W);
+/* Scratch for gcs_gabor_features: reflect-padded planar (pixel-128) pyramid levels. */
+size_t gcs_gabor_workspace_bytes(int B, int H, int W, int n_scales);
 
-/* SPEC.md §3: img_dev [B][H][W][3] uint8 -> feats_dev slab, D = 3*F, d = c*F + f.
+/* SPEC.md §3: img_dev [B][H][W][3] uint8 -> feats_dev slab (pyramid + filter bank + magnitude).
  * Fills the slot's first stage (script.py:30). Requires H, W >= 8. workspace_dev:
  * gcs_gabor_workspace_bytes() bytes of device scratch, contents undefined before and after. */
 int gcs_gabor_features(const uint8_t *img_dev, int B, int H, int W, const int8_t *packed_dev,
-                       const int32_t *bias_dev, int n_filters, int shift, void *workspace_dev,
+                       const int32_t *bias_dev, int n_scales, int n_orient, int shift, void *workspace_dev,
                        uint16_t *feats_dev, gcs_stream_t stream);
 
-/* Slab -> canonical [B][D][H][W] uint16 (tests / debugging). */
-int gcs_features_unpack(const uint16_t *feats_dev, int B, int H, int W, int D, uint16_t *out_dev,
-                        gcs_stream_t stream);
+/* Slab -> canonical [B][D][H][W] uint16 (level-L responses replicated over 2^L blocks; tests / debugging). */
+int gcs_features_unpack(const uint16_t *feats_dev, int B, int H, int W, int n_scales, int n_orient,
+                        uint16_t *out_dev, gcs_stream_t stream);
 
 /* SPEC.md §4 init. n_sets == B: per-image codebooks (set s from image s); n_sets == 1:
  * global codebook from image 0. centroids_dev: uint16 [n_sets][k][D]. */
-int gcs_kmeans_init(const uint16_t *feats_dev, int B, int H, int W, int D, int k, int n_sets,
-                    uint16_t *centroids_dev, gcs_stream_t stream);
+int gcs_kmeans_init(const uint16_t *feats_dev, int B, int H, int W, int n_scales, int n_orient, int k,
+                    int n_sets, uint16_t *centroids_dev, gcs_stream_t stream);
 
-/* Features of n pixels: out_dev[i][0..D) = features of pixel byx_dev[i] = (b, y, x) (int32 triples,
+/* out_dev uint16 [n][D] = feature vectors of the n pixels byx_dev[i] = (image, row, col) (int32 triples in
  * device memory); b < 0 yields a zero row. Used to publish init centroids when one image is
  * sharded by rows over several ranks (BASELINE config 5). */
-int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int D, int n,
+int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int n_scales, int n_orient, int n,
                         const int32_t *byx_dev, uint16_t *out_dev, gcs_stream_t stream);
 
 /* SPEC.md §4 assign + per-workgroup partial sums (one streaming pass over the slab).
@@ -99,8 +101,8 @@ int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int D, i
  * the matrix cores, wider feature vectors on a generic VALU pass; k <= GCS_K_MAX. The same n_sets must be passed
  * to the reduce call that follows (it selects the partial layout). */
 int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
-                                 int H, int W, int D, int k, int n_sets, int row_lo, int row_hi,
-                                 int reverse, uint8_t *labels_dev, uint64_t *partials_dev,
+                                 int H, int W, int n_scales, int n_orient, int k, int n_sets, int row_lo,
+                                 int row_hi, int reverse, uint8_t *labels_dev, uint64_t *partials_dev,
                                  gcs_stream_t stream);
 
 /* partials -> sums_dev int64 [n_sets][k][D+1] ([..][D] = count). Deterministic slab
@@ -122,6 +124,14 @@ int gcs_kmeans_reduce_finalize(const uint64_t *partials_dev, int B, int H, int W
 /* Label slab -> int32 [B][H][W] (the dtype handed to metrics.py:43). */
 int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *out_dev,
                      gcs_stream_t stream);
+/* Label slab -> uint8 [B][H][W]: a quarter of the bytes for the device-to-host copy of the slot's host path
+ * (script.py:30 returns a host array); the host widens it (metrics.py:43 casts to int anyway). */
+int gcs_labels_raster_u8(const uint8_t *labels_dev, int B, int H, int W, uint8_t *out_dev,
+                         gcs_stream_t stream);
+
+/* Test hook: counts in *bad_dev (uint32, device) the 4096-value chunks of [0, n_max] on which the kernels' 7-instruction
+ * exact integer square root (SPEC.md §3: n <= 2 * 32642^2) is wrong. Expected 0. */
+int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_t stream);
 
 /* ---- boundary scoring of one image -------------------------------------- */
 

@@ -18,6 +18,15 @@ def load():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads of the C oracle (results do not depend on it: integer arithmetic)."""
+    load().oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(load().oracle_max_threads())
+
+
 def gabor_features(img, tapq, shift, n_orient):
     img = np.ascontiguousarray(img, np.uint8)
     tapq = np.ascontiguousarray(tapq, np.int16)

@@ -11,6 +11,27 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* The loops below are parallelised with OpenMP where iterations are independent (rows of a response, pixels of an
+ * assign pass with per-thread integer sums): integer arithmetic, so the result does not depend on the thread count.
+ * oracle_set_threads(1) gives the single-thread baseline bench.py reports. */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 static inline int refl(int i, int n) {
     /* scipy.ndimage mode='reflect' (d c b a | a b c d | d c b a), any distance */
@@ -51,6 +72,7 @@ static void pyramid_down(const uint8_t *src, int Hs, int Ws, uint8_t *dst) {
 /* One filter on one level image: lev [Hl][Wl][3] u8, channel c -> g [Hl][Wl] u16 (SPEC.md §3 response). */
 static void level_response(const uint8_t *lev, int Hl, int Wl, int c, const int16_t *tre, const int16_t *tim, int ks,
                            int shift, const int *ry, const int *rx, uint16_t *g) {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < Hl; ++y)
         for (int x = 0; x < Wl; ++x) {
             int64_t vre = 0, vim = 0;
@@ -124,20 +146,32 @@ int oracle_kmeans(const uint16_t *feats, int nimg, int D, long P, int k, int n_i
         memset(cnt, 0, sizeof(int64_t) * (size_t)k);
         for (int b = 0; b < nimg; ++b) {
             const uint16_t *fb = feats + (size_t)b * D * P;
-            for (long p = 0; p < P; ++p) {
-                int64_t best = 0;
-                int bj = 0;
-                for (int j = 0; j < k; ++j) {
-                    int64_t dist = 0;
-                    for (int d = 0; d < D; ++d) {
-                        const int64_t df = (int64_t)fb[(size_t)d * P + p] - c[(size_t)j * D + d];
-                        dist += df * df;
+#pragma omp parallel
+            {
+                int64_t *lsum = (int64_t *)calloc((size_t)k * D + k, sizeof(int64_t));   /* per-thread sums | counts */
+                int64_t *lcnt = lsum + (size_t)k * D;
+#pragma omp for schedule(static)
+                for (long p = 0; p < P; ++p) {
+                    int64_t best = 0;
+                    int bj = 0;
+                    for (int j = 0; j < k; ++j) {
+                        int64_t dist = 0;
+                        for (int d = 0; d < D; ++d) {
+                            const int64_t df = (int64_t)fb[(size_t)d * P + p] - c[(size_t)j * D + d];
+                            dist += df * df;
+                        }
+                        if (j == 0 || dist < best) { best = dist; bj = j; }
                     }
-                    if (j == 0 || dist < best) { best = dist; bj = j; }
+                    labels[(size_t)b * P + p] = bj;
+                    lcnt[bj]++;
+                    for (int d = 0; d < D; ++d) lsum[(size_t)bj * D + d] += fb[(size_t)d * P + p];
                 }
-                labels[(size_t)b * P + p] = bj;
-                cnt[bj]++;
-                for (int d = 0; d < D; ++d) sum[(size_t)bj * D + d] += fb[(size_t)d * P + p];
+#pragma omp critical
+                {
+                    for (int i = 0; i < k * D; ++i) sum[i] += lsum[i];
+                    for (int j = 0; j < k; ++j) cnt[j] += lcnt[j];
+                }
+                free(lsum);
             }
         }
         if (t < n_iter - 1)

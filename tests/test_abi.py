@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 10
+    assert lib.gcs_abi_version() == 11
 
 
 def test_no_torch_types_in_the_abi():
@@ -31,88 +31,108 @@ def test_no_torch_types_in_the_abi():
 
 
 def test_geometry(lib):
-    assert lib.gcs_feature_pitch(481) == 488 and lib.gcs_feature_pitch(321) == 328 and lib.gcs_feature_pitch(8) == 8
-    ps = lib.gcs_feature_plane_stride(321, 481)
-    assert ps % 256 == 0 and 0 <= ps - 321 * 488 < 256
-    assert lib.gcs_feature_slab_bytes(64, 321, 481, 72) == 64 * 72 * ps * 2
-    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * ps
-    assert lib.gcs_bank_packed_bytes(24) == 3 * 8 * 64 * 16 and lib.gcs_bank_packed_bytes(1) == 8 * 64 * 16
-    assert lib.gcs_bank_bias_count(24) == 24 and lib.gcs_bank_bias_count(25) == 32
+    """Pyramid slab (csrc/common.h): 8x8 blocks, four per tile; level L keeps 1/4^L of the pixels."""
+    blocks = 61 * 41                                            # ceil(481/8) x ceil(321/8)
+    tiles = (blocks + 3) // 4
+    tile_bytes = 36 * 256 * 2 + 36 * 64 * 2                     # 4x6 bank: 12 filters x 3 channels on levels 0 and 1
+    assert lib.gcs_feature_slab_bytes(64, 321, 481, 4, 6) == 64 * tiles * tile_bytes
+    assert lib.gcs_feature_slab_bytes(1, 321, 481, 8, 8) == tiles * 48 * (256 + 64 + 16 + 4) * 2
+    assert lib.gcs_feature_slab_bytes(1, 321, 481, 7, 1) == tiles * (6 * 512 + 6 * 128 + 6 * 32 + 32)   # 3 planes x 4 px x 2 B = 24 -> 32
+    assert lib.gcs_feature_slab_bytes(1, 8, 8, 1, 1) == 3 * 512
+    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * tiles * 256
+    assert lib.gcs_bank_packed_bytes(4, 6) == 4 * 8 * 64 * 16          # 12 filters per level -> 2 row tiles each
+    assert lib.gcs_bank_packed_bytes(1, 1) == 8 * 64 * 16 and lib.gcs_bank_packed_bytes(8, 8) == 8 * 8 * 64 * 16
+    assert lib.gcs_bank_bias_count(4, 6) == 32 and lib.gcs_bank_bias_count(3, 9) == 24 + 16
+    assert lib.gcs_bank_packed_bytes(9, 1) == 0 and lib.gcs_bank_packed_bytes(0, 1) == 0
     p = lib.gcs_kmeans_parts_per_image(64, 321, 481)
-    assert p == 12 and 321 * 488 / p <= 65536                 # 64 * 12 = 768 workgroups = 256 CUs x 3
-    assert lib.gcs_kmeans_parts_per_image(1, 321, 481) * 8 * 256 <= ps          # >= 8 tiles per workgroup
+    assert p == 12 and tiles * 256 / p <= 65536                # 64 * 12 = 768 workgroups = 256 CUs x 3
+    assert lib.gcs_kmeans_parts_per_image(1, 321, 481) * 8 <= tiles                      # >= 8 tiles per workgroup
     assert lib.gcs_kmeans_parts_per_image(1, 2048, 2048) * 65536 >= 2048 * 2048
-    assert lib.gcs_kmeans_parts_per_image(4096, 321, 481) * 65536 >= 321 * 488
+    assert lib.gcs_kmeans_parts_per_image(4096, 321, 481) * 65536 >= tiles * 256
     assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * 8 * 73 * 8
-    assert lib.gcs_feature_slab_bytes(0, 1, 1, 1) == 0
+    assert lib.gcs_feature_slab_bytes(0, 1, 1, 1, 1) == 0
+    assert lib.gcs_gabor_workspace_bytes(1, 321, 481, 4) > 3 * (321 + 14) * (481 + 14) + 3 * (161 + 14) * (241 + 14)
+    assert lib.gcs_gabor_workspace_bytes(1, 321, 481, 9) == 0
 
 
 def _pack(lib, bank):
-    nf = bank.n_filters
-    packed = np.zeros(lib.gcs_bank_packed_bytes(nf), np.int8)
-    bias = np.zeros(lib.gcs_bank_bias_count(nf), np.int32)
+    ns, no = bank.n_scales, bank.n_orient
+    packed = np.zeros(lib.gcs_bank_packed_bytes(ns, no), np.int8)
+    bias = np.zeros(lib.gcs_bank_bias_count(ns, no), np.int32)
     tq = np.ascontiguousarray(bank.tapq)
-    rc = lib.gcs_bank_pack(tq.ctypes.data, nf, bank.ksize, packed.ctypes.data, bias.ctypes.data)
+    rc = lib.gcs_bank_pack(tq.ctypes.data, ns, no, bank.ksize, packed.ctypes.data, bias.ctypes.data)
     return rc, packed, bias
 
 
 @pytest.mark.parametrize("kw", [{}, dict(n_scales=2, n_orient=3, ksize=7), dict(n_scales=1, n_orient=1, ksize=1),
-                                dict(n_scales=8, n_orient=8)])
+                                dict(n_scales=8, n_orient=8), dict(n_scales=3, n_orient=9, ksize=9)])
 def test_bank_pack_layout(lib, kw):
-    """packed[mt][kk][lane][j] = digit(part) of tap (dy=2kk+h, dx=j) of filter 8mt + r/4 (gcs.hip)."""
+    """Level by level (filters of scales 2L, 2L+1), each level on fresh row tiles:
+    packed[tile][kk][lane][j] = digit(part) of tap (dy=2kk+h, dx=j) of the level's filter 8mt + r/4 (csrc/abi.hip)."""
     bank = make_bank(**kw)
     rc, packed, bias = _pack(lib, bank)
     assert rc == 0
-    nf, ks = bank.n_filters, bank.ksize
+    nf, ks, no = bank.n_filters, bank.ksize, bank.n_orient
     lo, hi = split_digits(bank.tapq)
     off = (15 - ks) // 2
     frame = np.zeros((nf, 4, 16, 16), np.int8)           # part order: re_lo, re_hi, im_lo, im_hi
     for part, (dig, ri) in enumerate([(lo, 0), (hi, 0), (lo, 1), (hi, 1)]):
         frame[:, part, off:off + ks, off:off + ks] = dig[:, ri]
-    mt_n = (nf + 7) // 8
-    pk = packed.reshape(mt_n, 8, 64, 16)
-    for mt in range(mt_n):
-        for kk in range(8):
-            for lane in (0, 1, 5, 31, 32, 47, 63):
-                r, h = lane & 31, lane >> 5
-                f, part = 8 * mt + r // 4, r & 3
-                want = frame[f, part, 2 * kk + h] if f < nf else np.zeros(16, np.int8)
-                assert np.array_equal(pk[mt, kk, lane], want)
-    assert np.array_equal(bias[:nf], 128 * bank.tapq[:, 0].astype(np.int64).sum(axis=(1, 2)))
-    assert np.all(bias[nf:] == 0)
+    pk = packed.reshape(-1, 8, 64, 16)
+    tile0 = 0
+    for lv in range(bank.n_levels):
+        f0 = 2 * lv * no
+        fl_n = min(nf, f0 + 2 * no) - f0
+        mt_n = (fl_n + 7) // 8
+        for mt in range(mt_n):
+            for kk in range(8):
+                for lane in (0, 1, 5, 31, 32, 47, 63):
+                    r, h = lane & 31, lane >> 5
+                    fl, part = 8 * mt + r // 4, r & 3
+                    want = frame[f0 + fl, part, 2 * kk + h] if fl < fl_n else np.zeros(16, np.int8)
+                    assert np.array_equal(pk[tile0 + mt, kk, lane], want)
+        want_bias = np.zeros(8 * mt_n, np.int64)
+        want_bias[:fl_n] = 128 * bank.tapq[f0:f0 + fl_n, 0].astype(np.int64).sum(axis=(1, 2))
+        assert np.array_equal(bias[8 * tile0:8 * (tile0 + mt_n)], want_bias)
+        tile0 += mt_n
+    assert tile0 == pk.shape[0]
 
 
 def test_bank_pack_rejects_bad_input(lib):
     bank = make_bank()
     tq = np.ascontiguousarray(bank.tapq)
-    packed = np.zeros(lib.gcs_bank_packed_bytes(24), np.int8)
-    bias = np.zeros(24, np.int32)
-    assert lib.gcs_bank_pack(None, 24, 15, packed.ctypes.data, bias.ctypes.data) == 1
-    assert lib.gcs_bank_pack(tq.ctypes.data, 0, 15, packed.ctypes.data, bias.ctypes.data) == 1
-    assert lib.gcs_bank_pack(tq.ctypes.data, 24, 16, packed.ctypes.data, bias.ctypes.data) == 1
+    packed = np.zeros(lib.gcs_bank_packed_bytes(4, 6), np.int8)
+    bias = np.zeros(lib.gcs_bank_bias_count(4, 6), np.int32)
+    assert lib.gcs_bank_pack(None, 4, 6, 15, packed.ctypes.data, bias.ctypes.data) == 1
+    assert lib.gcs_bank_pack(tq.ctypes.data, 0, 6, 15, packed.ctypes.data, bias.ctypes.data) == 1
+    assert lib.gcs_bank_pack(tq.ctypes.data, 9, 6, 15, packed.ctypes.data, bias.ctypes.data) == 1      # more than 4 levels
+    assert lib.gcs_bank_pack(tq.ctypes.data, 4, 6, 16, packed.ctypes.data, bias.ctypes.data) == 1
     assert b"ksize" in lib.gcs_last_error()
     bad = tq.copy()
     bad[0, 1, 0, 0] += 1                                  # imaginary part no longer sums to zero
-    assert lib.gcs_bank_pack(bad.ctypes.data, 24, 15, packed.ctypes.data, bias.ctypes.data) == 1
+    assert lib.gcs_bank_pack(bad.ctypes.data, 4, 6, 15, packed.ctypes.data, bias.ctypes.data) == 1
 
 
 def test_device_entry_points_validate_before_launching(lib):
     """Argument errors are reported without touching the GPU (so this runs on the CPU box)."""
     one = C.c_void_p(16)                                   # non-NULL dummy, never dereferenced
-    assert lib.gcs_gabor_features(None, 1, 16, 16, one, one, 24, 11, one, one, None) == 1
-    assert lib.gcs_gabor_features(one, 1, 7, 16, one, one, 24, 11, one, one, None) == 1      # H < 8
-    assert lib.gcs_gabor_features(one, 0, 16, 16, one, one, 24, 11, one, one, None) == 1
-    assert lib.gcs_kmeans_init(one, 2, 16, 16, 72, 17, 2, one, None) == 1             # k > 16
-    assert lib.gcs_kmeans_init(one, 4, 16, 16, 72, 8, 3, one, None) == 1              # n_sets not in {1,B}
-    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 72, 0, 1, 0, 16, 0, one, one, None) == 1
-    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 72, 8, 1, 4, 4, 0, one, one, None) == 1   # empty row window
-    assert lib.gcs_features_gather(one, 1, 16, 16, 72, 0, one, one, None) == 1
+    assert lib.gcs_gabor_features(None, 1, 16, 16, one, one, 4, 6, 11, one, one, None) == 1
+    assert lib.gcs_gabor_features(one, 1, 7, 16, one, one, 4, 6, 11, one, one, None) == 1      # H < 8
+    assert lib.gcs_gabor_features(one, 0, 16, 16, one, one, 4, 6, 11, one, one, None) == 1
+    assert lib.gcs_gabor_features(one, 1, 16, 16, one, one, 9, 6, 11, one, one, None) == 1     # more than 4 pyramid levels
+    assert lib.gcs_kmeans_init(one, 2, 16, 16, 4, 6, 17, 2, one, None) == 1             # k > 16
+    assert lib.gcs_kmeans_init(one, 4, 16, 16, 4, 6, 8, 3, one, None) == 1              # n_sets not in {1,B}
+    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 0, 1, 0, 16, 0, one, one, None) == 1
+    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 8, 1, 4, 4, 0, one, one, None) == 1   # empty row window
+    assert lib.gcs_features_gather(one, 1, 16, 16, 4, 6, 0, one, one, None) == 1
     assert lib.gcs_kmeans_reduce(None, 1, 16, 16, 72, 8, 1, one, None) == 1
     assert lib.gcs_kmeans_finalize(one, 0, 8, 72, one, None) == 1
     assert lib.gcs_kmeans_reduce_finalize(one, 1, 16, 16, 72, 8, 1, one, None, None) == 1     # no centroids
     assert lib.gcs_kmeans_reduce_finalize(one, 2, 16, 16, 72, 8, 3, None, one, None) == 1     # n_sets not in {1,B}
     assert lib.gcs_labels_widen(one, 1, 0, 16, one, None) == 1
-    assert lib.gcs_features_unpack(one, 1, 16, 16, 0, one, None) == 1
+    assert lib.gcs_features_unpack(one, 1, 16, 16, 0, 6, one, None) == 1
+    assert lib.gcs_labels_raster_u8(one, 1, 16, 0, one, None) == 1
+    assert lib.gcs_selftest_isqrt(10, None, None) == 1
     assert lib.gcs_boundary_counts(one, one, 0, 16, 16, one, one, None) == 1
     assert lib.gcs_connected_regions(one, 0, 16, 16, one, one, None) == 1
     assert lib.gcs_region_counts(one, one, 0, 16, 16, 8, 4, one, one, one, None) == 1         # no annotators

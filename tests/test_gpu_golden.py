@@ -151,3 +151,42 @@ def test_sixty_four_filter_bank_full_segment(built):
     got = s.segment_batch(imgs, mode="global")
     tapq, shift = so.bank(8, 8)
     assert np.array_equal(got, co.segment_batch(imgs, tapq, shift, 8, k=6, n_iter=3, mode="global"))
+
+
+def test_batch64_full_size_global_codebook_vs_c_oracle(seg):
+    """The configuration bench.py times (BASELINE config 2: 64 synthetic 481x321 images, seed 0, 4x6 bank, k = 8,
+    n_iter = 10, one global codebook; 768 k-means workgroups with 12 partial rows per image, reverse sweeps): EVERY
+    pixel of all 64 label maps against the C oracle (OpenMP over the host cores, ~20 s on the GPU box's 16)."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(64, 321, 481, seed=0)
+    got = seg.segment_batch(imgs, mode="global")
+    ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, 6, mode="global")
+    assert got.shape == ref.shape == (64, 321, 481)
+    assert np.array_equal(got, ref), f"{(got != ref).mean():.4%} of pixels differ"
+    assert len(np.unique(got)) == 8
+
+
+def test_batch64_full_size_per_image_codebooks_vs_c_oracle(seg):
+    """Same batch, the reference's semantics (script.py:22-38: every image on its own): six of the 64 label maps
+    (first, last and four in between) against the C oracle."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(64, 321, 481, seed=0)
+    got = seg.segment_batch(imgs)
+    pick = [0, 7, 21, 42, 50, 63]
+    ref = co.segment_batch(imgs[pick], seg.bank.tapq, seg.bank.shift, 6)
+    assert np.array_equal(got[pick], ref)
+
+
+def test_config4_full_size_vs_c_oracle(built):
+    """BASELINE config 4 (8x8 = 64-filter bank, D = 192, four pyramid levels) at full image size: features of one
+    481x321 image and the global-codebook labels of a batch of two, against the C oracle."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(2, 321, 481, seed=44)
+    s = Segmenter(n_scales=8, n_orient=8, n_iter=5)
+    tapq, shift = so.bank(8, 8)
+    got = s.features_device(torch.from_numpy(imgs[:1]).cuda()).cpu().numpy().view(np.uint16)[0]
+    assert np.array_equal(got, co.gabor_features(imgs[0], tapq, shift, 8))
+    lab = s.segment_batch(imgs, mode="global")
+    assert np.array_equal(lab, co.segment_batch(imgs, tapq, shift, 8, n_iter=5, mode="global"))

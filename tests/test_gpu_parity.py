@@ -138,3 +138,33 @@ def test_randomised_shapes_banks_and_codebooks(torch_cuda):
             ref = np.stack([so.connected_regions(r) for r in ref])
         assert np.array_equal(got, ref), dict(case=case, h=h, w=w, b=b, bank=(ns, no, ks), k=k, n_iter=n_iter,
                                               mode=mode, conn=conn, wrong=float((got != ref).mean()))
+
+
+def test_isqrt31_exhaustive(torch_cuda):
+    """The 7-instruction exact integer square root of the Gabor epilogue (csrc/gabor.hip isqrt31) on EVERY n of its
+    domain, 0 ... 2 * 32642^2 (SPEC.md §3 bound on re^2 + im^2): one kernel, 2.1e9 values."""
+    import ctypes as C
+    from gabor_color_image_segmentation_amd import _lib
+    torch = torch_cuda
+    lib = _lib.load()
+    bad = torch.full((1,), 123, dtype=torch.int32, device="cuda")
+    n_max = 2 * 32642 ** 2
+    _lib.check(lib.gcs_selftest_isqrt(n_max, bad.data_ptr(), torch.cuda.current_stream().cuda_stream), "selftest")
+    assert int(bad.item()) == 0
+
+
+def test_pyramid_levels_with_odd_sizes_and_deep_banks(torch_cuda):
+    """Images whose every pyramid level has an odd size (edge replication on each level), banks of 1..4 levels with one
+    or two scales on the last level: canonical features against the NumPy oracle."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    torch = torch_cuda
+    for (h, w), (ns, no) in [((73, 101), (8, 2)), ((41, 57), (7, 3)), ((67, 35), (5, 1)), ((24, 120), (6, 4)),
+                             ((9, 9), (8, 1)), ((8, 8), (3, 2))]:
+        imgs = _synth(2, h, w, seed=h + w)
+        seg = Segmenter(n_scales=ns, n_orient=no)
+        got = seg.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)
+        tapq, shift = so.bank(ns, no)
+        for b in range(2):
+            ref = so.gabor_features(imgs[b], tapq, shift, no)
+            bad = np.argwhere(got[b] != ref)
+            assert bad.size == 0, ((h, w), (ns, no), len(bad), bad[:4])
