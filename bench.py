@@ -26,8 +26,35 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x bf16 (~2.5 PF), same guide, Matrix cores table
 
 
-def _oracle_worker(args):
-    """Runs in a spawned process: oracle only, never touches the GPU."""
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a GPU
+    box hands a 1-GPU job a share of a many-core host; oversubscribing that share with one thread per visible core
+    makes an OpenMP run crawl)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except Exception:
+            pass
+    cores = min(n, quota) if quota else n
+    cap = int(os.environ.get("GCS_BENCH_CORES", "0"))
+    return (min(cores, cap) if cap > 0 else cores), n, quota
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def _numpy_worker(args):
+    """Runs in a spawned process: the NumPy + scipy oracle on ONE image, never touches the GPU."""
     idx, k, n_iter = args
     import time as _t
     from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
@@ -39,30 +66,57 @@ def _oracle_worker(args):
         pass
     img = synthetic_shard(idx, 1, H, W, seed=0)[0]
     t0 = _t.perf_counter()
-    lab = spec_oracle.segment(img, k=k, n_iter=n_iter)
-    return idx, _t.perf_counter() - t0, lab
+    spec_oracle.segment(img, k=k, n_iter=n_iter)
+    return _t.perf_counter() - t0
 
 
-def cpu_baseline(k, n_iter):
-    """The oracle (NumPy/scipy port of SPEC.md) timed on the host: one worker process per core,
-    one image of the same synthetic batch per worker (bounded sample), plus the single-thread rate.
-    It is the checker, timed as the reported CPU baseline only. Workers are *spawned* (no fork after
-    HIP initialisation) and never import torch.cuda."""
+def _c_oracle_worker(args):
+    """Runs in a spawned process (OpenMP inside): the C restatement of SPEC.md on the WHOLE timed batch, same
+    codebook mode, so that every label of the configuration bench.py times can be compared with the GPU result."""
+    batch, k, n_iter, mode, threads = args
+    os.environ["OMP_WAIT_POLICY"] = "PASSIVE"          # idle OpenMP threads sleep instead of spinning on a CPU share
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import time as _t
+    from gabor_color_image_segmentation_amd import make_bank
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+    from oracle import c_oracle
+    bank = make_bank()
+    imgs = synthetic_shard(0, batch, H, W, seed=0)
+    c_oracle.set_threads(1)
+    t0 = _t.perf_counter()
+    c_oracle.segment_batch(imgs[:1], bank.tapq, bank.shift, bank.n_orient, k=k, n_iter=n_iter, mode="per_image")
+    single = _t.perf_counter() - t0
+    c_oracle.set_threads(threads)
+    t0 = _t.perf_counter()
+    lab = c_oracle.segment_batch(imgs, bank.tapq, bank.shift, bank.n_orient, k=k, n_iter=n_iter, mode=mode)
+    return _t.perf_counter() - t0, single, lab.astype("uint8")
+
+
+def cpu_baseline(batch, k, n_iter, mode):
+    """CPU path timed on the host beside the GPU. The oracle is the checker; here it is also the
+    reported baseline, never the product. Spawned workers only (no fork after HIP initialisation).
+
+    * `value`: the C restatement (oracle/gcs_oracle.c, OpenMP on every core this process may use) on the whole timed
+      batch in the timed codebook mode; its labels are compared with the GPU's, pixel for pixel, all images.
+    * `c_single_thread_mpix_s`: the same code, one thread, one image, running alone.
+    * `numpy_single_thread_mpix_s`: the NumPy + scipy.ndimage oracle (oracle/spec_oracle.py), one worker running alone.
+    """
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    cores, affinity, quota = usable_cores()
     ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map(_oracle_worker, [(0, k, 1)] * cores)            # warm the workers (imports, page-in)
-        t0 = time.perf_counter()
-        res = pool.map(_oracle_worker, [(i, k, n_iter) for i in range(cores)])
-        wall = time.perf_counter() - t0
-    single = sum(r[1] for r in res) / len(res)
-    ref0 = [r[2] for r in res if r[0] == 0][0]
-    return ref0, dict(value=round(cores * H * W / wall / 1e6, 4), unit="Mpix/s", cores=cores, kind="port",
-                      seconds=round(wall, 2), single_thread_mpix_s=round(H * W / single / 1e6, 5),
-                      sample=f"images 0..{cores - 1} of the {PER_GPU} synthetic {W}x{H}x3 images, same bank/k/n_iter, "
-                             f"NumPy+scipy.ndimage oracle, one single-threaded worker process per core "
-                             f"({cores} of {os.cpu_count()} host cores)")
+    with ctx.Pool(1) as pool:
+        log(f"cpu baseline: C oracle on {cores} threads (affinity {affinity}, cgroup quota {quota}, cpu_count {os.cpu_count()})")
+        wall, c_single, ref = pool.apply_async(_c_oracle_worker, [(batch, k, n_iter, mode, cores)]).get(timeout=600)
+        log(f"cpu baseline: C oracle {wall:.1f} s; NumPy oracle, one image")
+        np_single = pool.apply_async(_numpy_worker, [(0, k, n_iter)]).get(timeout=300)
+    return ref, dict(value=round(batch * H * W / wall / 1e6, 3), unit="Mpix/s", cores=cores, kind="port",
+                     seconds=round(wall, 2), host_cpu_count=os.cpu_count(), affinity_cores=affinity,
+                     cgroup_cpu_quota=quota,
+                     c_single_thread_mpix_s=round(H * W / c_single / 1e6, 4),
+                     numpy_single_thread_mpix_s=round(H * W / np_single / 1e6, 4),
+                     sample=f"all {batch} synthetic {W}x{H}x3 images of the timed batch, same bank/k/n_iter, {mode} "
+                            f"codebook: C restatement of SPEC.md with OpenMP on {cores} threads (affinity {affinity}, cgroup quota {quota}, "
+                            f"os.cpu_count() = {os.cpu_count()}); single-thread figures: one image, run alone")
 
 
 class TimedOps:
@@ -120,7 +174,7 @@ def main():
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
-    ap.add_argument("--also-other-mode", action="store_true", help="also time the other codebook mode (extra key)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other codebook mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--spinup-steps", type=int, default=15, help="device clock spin-up before the warm-up steps (0 = none)")
@@ -190,6 +244,7 @@ def main():
     # Device spin-up (not a bench step, outside every timed region): the GPU leaves its idle clock state only after
     # ~30 ms of matrix work (15 steps = ~50 ms); without it the first timed Gabor launches run ~10 % slower (0.89 vs 0.80 ms) when the
     # caller asks for very few warm-up steps.
+    log(f"rank {rank}: spin-up, warm-up and {args.steps} timed steps ({args.mode})")
     for _ in range(args.spinup_steps):       # a fixed count: every rank must issue the same collectives
         step(args.mode)
     torch.cuda.synchronize(dev)
@@ -198,26 +253,36 @@ def main():
     value = total_px * args.steps / dt / 1e6
 
     # per-kernel device time from the events recorded inside the timed region (rank 0's GPU)
-    D = seg.bank.n_features
-    F = seg.bank.n_filters
+    bank = seg.bank
+    D = bank.n_features
     px = B * H * W
     g_ms, g_n = tops.mean_ms("gabor")
     a_ms, a_n = tops.mean_ms("assign")
-    g_bytes = (3 + 2 * D) * px                       # u8 RGB in + u16 features out (SPEC.md §6)
-    a_bytes = (2 * D + 1) * px                       # u16 features in + u8 label out, per Lloyd pass
-    g_ops = 2 * seg.bank.ksize ** 2 * (4 * F) * 3 * px   # int8 MACs x2: 2 digits x {re,im} x F rows, 3 channels
+    # Algorithmic bytes. The slab keeps pyramid level L at 1/4^L of the pixels (SPEC.md §3), so the
+    # feature bytes per full-resolution pixel are 2 * sum_L D_L / 4^L (90 for the 4x6 bank) instead of 2D (144).
+    # `alg_bytes` is that pyramid-resident figure (the smaller, stricter denominator); `unfused_def_bytes` is
+    # SURVEY.md §8d's un-fused definition with uint16 features (3 + 2D, 2D + 1), kept for comparison with round 1.
+    lv = [(3 * min(2, bank.n_scales - 2 * L) * bank.n_orient, 4 ** L) for L in range(bank.n_levels)]
+    feat_b = 2 * sum(d / q for d, q in lv)
+    g_bytes = (3 + feat_b) * px                      # u8 RGB in + u16 pyramid features out
+    a_bytes = (feat_b + 1) * px                      # u16 pyramid features in + u8 label out, per Lloyd pass
+    g_ops = sum(2 * bank.ksize ** 2 * (4 * d // 3) * 3 * px / q for d, q in lv)   # int8 MACs x2: 2 digits x {re,im} x F_L rows
     kernels = {
-        "gabor_mfma_kernel": dict(launches=g_n, launches_per_step=1, avg_ms=round(g_ms, 4), alg_bytes=g_bytes, alg_ops=g_ops,
+        "gabor_mfma_kernel": dict(launches=g_n, launches_per_step=1, avg_ms=round(g_ms, 4), alg_bytes=int(g_bytes),
+                                  unfused_def_bytes=(3 + 2 * D) * px, alg_ops=int(g_ops),
                                   gbs=round(g_bytes / g_ms / 1e6, 1), tops=round(g_ops / g_ms / 1e9, 1),
                                   hbm_frac=round(g_bytes / g_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                  mfma_frac=round(g_ops / g_ms / 1e9 / I8_MFMA_PEAK_TOPS, 4)),
-        "kmeans_pass_mfma_kernel": dict(launches=a_n, launches_per_step=args.n_iter, avg_ms=round(a_ms, 4), alg_bytes=a_bytes,
+                                  mfma_frac=round(g_ops / g_ms / 1e9 / I8_MFMA_PEAK_TOPS, 4),
+                                  note="whole gcs_gabor_features call: pad / pyramid kernels + one MFMA launch per level"),
+        "kmeans_pass_mfma_kernel": dict(launches=a_n, launches_per_step=args.n_iter, avg_ms=round(a_ms, 4),
+                                     alg_bytes=int(a_bytes), unfused_def_bytes=(2 * D + 1) * px,
                                      gbs=round(a_bytes / a_ms / 1e6, 1),
-                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4)),
+                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                     unfused_def_gbs=round((2 * D + 1) * px / a_ms / 1e6, 1)),
     }
     if g_ms >= a_ms * args.n_iter:    # dominant = larger share of the step (`launches` = launches bracketed by events)
         kg = kernels["gabor_mfma_kernel"]
-        # arithmetic intensity 2*225*96*3/147 = 881 op/B is above the int8 ridge (5 POP/s / 8 TB/s =
+        # arithmetic intensity 81000 op / 93 B = 871 op/B is above the int8 ridge (5 POP/s / 8 TB/s =
         # 625 op/B): the MFMA roof bounds this kernel; the HBM fraction is reported next to it.
         roofline = dict(kernel="gabor_mfma_kernel", bound="mfma", achieved=kg["tops"], peak=I8_MFMA_PEAK_TOPS,
                         unit="TFLOP/s", frac=kg["mfma_frac"], traffic=None, ops="int8 MAC x2 (TOP/s)",
@@ -225,7 +290,10 @@ def main():
     else:
         ka = kernels["kmeans_pass_mfma_kernel"]
         roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ka["hbm_frac"], traffic=None)
+                        unit="GB/s", frac=ka["hbm_frac"], traffic=None,
+                        alg_bytes_def="pyramid-resident: (2*sum_L D_L/4^L + 1) B/px = 91 for the 4x6 bank; the un-fused "
+                                      "(2D+1) = 145 B/px definition gives unfused_def_gbs",
+                        unfused_def_gbs=ka["unfused_def_gbs"])
 
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
     # command (tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no profile matches.
@@ -245,26 +313,40 @@ def main():
 
     extra = {}
     other = "per_image" if args.mode == "global" else "global"
-    if world == 1 and args.also_other_mode:
-        dt2 = timed(other, max(1, args.steps // 2), 1, events=False)
-        extra[f"{other}_mpix_s"] = round(px * max(1, args.steps // 2) / dt2 / 1e6, 1)
+    if world == 1 and not args.no_other_mode:
+        # the other codebook mode (per_image = the reference's own semantics, script.py:22-38), same batch, same clock
+        log(f"timing the {other} codebook mode")
+        dt2 = timed(other, max(2, args.steps // 2), 2, events=False)
+        extra[f"{other}_mpix_s"] = round(px * max(2, args.steps // 2) / dt2 / 1e6, 1)
 
     if world == 1 and not args.no_host_path:
-        # the slot as the reference calls it: host uint8 array in, host int32 labels out (pageable memory,
-        # H2D 29.6 MB + D2H 39.5 MB per batch over PCIe). Reported beside `value`, never as `value`.
-        seg.segment_batch(imgs_np, mode=args.mode)
+        # the slot as the reference calls it (script.py:25,30): host uint8 array in, host label array out, PCIe both
+        # ways. Reported beside `value`, never as `value`.
+        cores_, _, _ = usable_cores()
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), cores_)))     # host-side copies: no more threads than cores
+        log(f"host-to-host path ({torch.get_num_threads()} host threads)")
+        for key, kw in (("host_to_host_mpix_s", {}), ("host_to_host_u8_mpix_s", dict(out_dtype=np.uint8))):
+            seg.segment_batch(imgs_np, mode=args.mode, **kw)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                seg.segment_batch(imgs_np, mode=args.mode, **kw)
+            extra[key] = round(px * 4 / (time.perf_counter() - t0) / 1e6, 1)
+        log("single-image latency")
+        one = imgs_np[0]
+        seg(one)
         t0 = time.perf_counter()
-        for _ in range(2):
-            seg.segment_batch(imgs_np, mode=args.mode)
-        extra["host_to_host_mpix_s"] = round(px * 2 / (time.perf_counter() - t0) / 1e6, 1)
+        for _ in range(20):
+            seg(one)
+        extra["single_image_latency_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ref, cpu = cpu_baseline(args.k, args.n_iter)
+        ref, cpu = cpu_baseline(B, args.k, args.n_iter, args.mode)
         if not args.no_check:
-            # parity of the timed configuration itself: per-image labels of image 0 vs the oracle
-            lab = seg.segment_device(imgs[:1], mode="per_image").cpu().numpy()[0]
+            # parity of the timed configuration itself: every label of the whole batch, timed mode, vs the C oracle
+            lab = seg.segment_device(imgs, mode=args.mode).to(torch.uint8).cpu().numpy()
             cpu["labels_match_gpu"] = bool(np.array_equal(lab, ref))
+            cpu["labels_compared"] = f"all {B} images, {args.mode} codebook, {lab.size} pixels"
 
     if rank == 0:
         line = dict(metric="Mpix/s segmented (Gabor+k-means), 481x321x3 batch", value=round(value, 1),
@@ -272,17 +354,19 @@ def main():
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="i8", data="synthetic",
                     config=dict(workload=f"batch {B}/GPU synthetic {W}x{H}x3 uint8 (seed 0), 4-scale x "
-                                         f"6-orientation Gabor bank ksize 15, k={args.k}, n_iter={args.n_iter}",
-                                codebook=args.mode, global_batch=world * B, features="uint16 Q7",
+                                         f"6-orientation Gabor bank ksize 15 on a 2-level octave pyramid, k={args.k}, "
+                                         f"n_iter={args.n_iter}",
+                                codebook=args.mode, global_batch=world * B, features="uint16 Q7, level L at 1/4^L resolution",
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"
                                 if args.mode == "global" else f"dp{world} (independent images)"),
                     roofline=roofline, cpu_baseline=cpu, kernels=kernels,
-                    # whole job against the HBM roof, un-fused definition of SURVEY.md §8d with the uint16 feature
-                    # denominators: (3 + 2D) + n_iter * (2D + 1) bytes per pixel, per GPU
-                    end_to_end=dict(alg_bytes_per_px=(3 + 2 * D) + args.n_iter * (2 * D + 1),
-                                    gbs_per_gpu=round(((3 + 2 * D) + args.n_iter * (2 * D + 1)) * px * args.steps / dt / 1e9, 1),
-                                    hbm_frac=round(((3 + 2 * D) + args.n_iter * (2 * D + 1)) * px * args.steps / dt / 1e9
-                                                   / HBM_PEAK_GBS, 4)),
+                    # whole job against the HBM roof: Gabor + n_iter passes, pyramid-resident bytes per pixel (and the
+                    # un-fused uint16 definition of SURVEY.md §8d beside it), per GPU
+                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * (feat_b + 1), 1),
+                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * (feat_b + 1)) * px * args.steps / dt / 1e9, 1),
+                                    hbm_frac=round(((3 + feat_b) + args.n_iter * (feat_b + 1)) * px * args.steps / dt / 1e9
+                                                   / HBM_PEAK_GBS, 4),
+                                    unfused_def_bytes_per_px=(3 + 2 * D) + args.n_iter * (2 * D + 1)),
                     **extra)
         print(json.dumps(line))
     if world > 1:

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -29,7 +29,7 @@ SIGNATURES = {
     "gcs_kmeans_parts_per_image": (_sz, [_i, _i, _i]),
     "gcs_kmeans_partial_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gcs_gabor_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_gabor_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_features_unpack": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_features_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

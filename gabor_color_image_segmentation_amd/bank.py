@@ -16,6 +16,7 @@ KSIZE_MAX = 15          # the HIP kernel's tap frame is 15 rows x 16 columns
 N_SCALES_MAX = 8        # octave pyramid of at most 4 levels (scales 2L, 2L+1 run on level L)
 TAPQ_MAX = 32639        # 127*256 + 127: largest value two signed byte digits hold
 FEATURE_Q = 7           # features are Q7 grey levels
+TAP_Q = 15              # taps are Q15 (less only for kernels so peaked that a tap would not fit two byte digits)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -45,7 +46,7 @@ class GaborBank:
         return (self.n_scales + 1) // 2
 
 
-def gabor_taps(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0),
+def gabor_taps(n_scales=4, n_orient=6, ksize=13, f_max=0.4, ratio=math.sqrt(2.0),
                bandwidth=1.0) -> np.ndarray:
     """Float64 taps ``[F, 2, ksize, ksize]`` (SPEC.md §2, before quantisation)."""
     if ksize % 2 != 1 or not (1 <= ksize <= KSIZE_MAX):
@@ -72,11 +73,11 @@ def gabor_taps(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0)
     return taps
 
 
-def make_bank(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0),
+def make_bank(n_scales=4, n_orient=6, ksize=13, f_max=0.4, ratio=math.sqrt(2.0),
               bandwidth=1.0) -> GaborBank:
-    """Quantise the bank to one global exponent (SPEC.md §2)."""
+    """Quantise the bank to Q15 taps (SPEC.md §2): shift = 8, i.e. the response's Q7 value is bytes 1..2 of v."""
     taps = gabor_taps(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
-    exponent = int(math.floor(math.log2(TAPQ_MAX / np.abs(taps).max())))
+    exponent = min(TAP_Q, int(math.floor(math.log2(TAPQ_MAX / np.abs(taps).max()))))
     tapq = np.rint(taps * 2.0 ** exponent).astype(np.int64)
     if np.abs(tapq).max() > TAPQ_MAX:
         raise AssertionError("tap quantisation overflowed the two-digit range")

@@ -27,19 +27,22 @@ __device__ __forceinline__ int reflect(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
-// floor(sqrt(n)) for n <= 2 * 32642^2 < 2^31 (SPEC.md §3 bound), exact, in 7 VALU ops
-// (measured on gfx950, tools/ubench/valu_ops2: v_cvt_u32_f32 ~3 ns and v_cmp+v_addc ~4.3 ns per
-// wave-instruction, against ~1.2 ns for an add):
+// floor(sqrt(n)) for n < 2^31 (SPEC.md §3 bound: n <= 2 * 32724^2), exact, in 6 VALU ops:
 //   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
 //   bits = r + 2^23 (as uint)          the sum has ulp 1: bits = 0x4B000000 + RNE(r), RNE(r) in {floor(s), floor(s)+1}
 //   qr^2 = v_mul_u32_u24(bits, bits)   the multiplier only sees the low 24 bits, i.e. qr = RNE(r) (< 2^16)
-//   q    = qr - (qr^2 > n)             sign arithmetic, one v_add3: bits - 0x4B000000 + ((int)(n - qr^2) >> 31);
-//                                      qr <= 46164 so qr^2 < 2^31 and the signed difference cannot overflow.
-// Exhaustively checked over the whole domain by tests/test_gpu_parity.py::test_isqrt31_exhaustive.
+//   q    = qr - (qr^2 > n)             v_cmp_gt_u32 + ONE v_subbrev_co_u32: bits - 0x4B000000 - carry
+// (v_cvt_f32_u32, v_sqrt_f32, v_add_f32, v_mul_u32_u24, v_cmp_gt_u32, v_subbrev_co_u32.) In this kernel every VALU
+// instruction costs ~4.2 cycles whatever its kind (PMC, profiles/r1_notes.md), so the count is what matters.
+// Exhaustively checked over [0, 2^31) by tests/test_gpu_parity.py::test_isqrt31_exhaustive.
 __device__ __forceinline__ unsigned isqrt31(unsigned n) {
     const unsigned bits = __float_as_uint(__builtin_amdgcn_sqrtf((float)n) + 8388608.0f);
-    const int d = (int)(n - __umul24(bits, bits));
-    return bits - 0x4B000000u + (unsigned)(d >> 31);
+    const unsigned sq = __umul24(bits, bits);
+    unsigned q;
+    // (the magic constant sits in a VGPR: a literal and the carry-in would both need the constant bus)
+    asm("v_cmp_gt_u32 vcc, %1, %2\n\tv_subbrev_co_u32 %0, vcc, %4, %3, vcc"
+        : "=v"(q) : "v"(sq), "v"(n), "v"(bits), "v"(0x4B000000u) : "vcc");
+    return q;
 }
 
 // out[i] = 1 if isqrt31 is wrong anywhere in [i * chunk, (i+1) * chunk) ∩ [0, n_max] (test hook; SPEC.md §3 domain)
@@ -136,7 +139,11 @@ constexpr int GCS_GABOR_MTMAX = 2;   // row tiles per launch: 3 needs ~250 VGPRs
 
 // One pyramid level. MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that
 // exist in the last row tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
-template <int MT, int GLAST>
+// KS = K-steps of 2 tap rows: 8 for a 15-row frame, 7 when ksize <= 13 (its rows 1..13 of the frame: the last K-step
+// would multiply zeros). SH8: shift == 8 (Q15 taps, SPEC.md §2): the Q7 response is bytes 1..2 of v, so ONE byte permute
+// packs (a_re, a_im) as int16 pairs and ONE v_dot2_i32_i16 gives re^2 + im^2 (|a| <= 32724 fits int16).
+typedef short v2s __attribute__((ext_vector_type(2)));
+template <int MT, int GLAST, int KS, bool SH8>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int HL, int Hp, int Wp, const int8_t *__restrict__ apack,
     const int32_t *__restrict__ bias, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int pitchL,
@@ -173,11 +180,11 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     };
 
     // ---- the whole A operand lives in registers: MT x 8 lane-linear 16-byte fragments
-    v4i afr[MT][8];
+    v4i afr[MT][KS];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int kk = 0; kk < KS; ++kk)
             afr[mt][kk] = reinterpret_cast<const v4i *>(apack)[((size_t)mt * 8 + kk) * 64 + lane];
 
     // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
@@ -214,9 +221,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 8*li + 4*qq
-                int win[8][5];
+                int win[KS][5];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
+                for (int kk = 0; kk < KS; ++kk) {
                     const int *rp = reinterpret_cast<const int *>(&s_tile[buf][c][trow + 2 * kk + h][8 * li + 4 * qq]);
 #pragma unroll
                     for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     // the wave inside its MFMA chain outranks the one in its (pure VALU) epilogue: -2.5 % (A/B)
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
+                    for (int kk = 0; kk < KS; ++kk) {
                         // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
                         v4i bf;
 #pragma unroll
@@ -253,9 +260,16 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                         for (int g = 0; g < 4; ++g) {
                             if (mt == MT - 1 && g >= GLAST) continue;
                             // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22), not a shift (slow here)
-                            const int a_re = (__mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g + 0] + bias_v[mt][g]) >> shift;
-                            const int a_im = (__mul24(acc[mt][4 * g + 3], 256) + acc[mt][4 * g + 2]) >> shift;
-                            const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                            const int v_re = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g + 0] + bias_v[mt][g];
+                            const int v_im = __mul24(acc[mt][4 * g + 3], 256) + acc[mt][4 * g + 2];
+                            unsigned n;
+                            if (SH8) {
+                                const unsigned pk = __builtin_amdgcn_perm((unsigned)v_re, (unsigned)v_im, 0x06050201u);
+                                n = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk), __builtin_bit_cast(v2s, pk), 0, false);
+                            } else {
+                                const int a_re = v_re >> shift, a_im = v_im >> shift;
+                                n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                            }
                             mag[mt][g] = isqrt31(n);
                         }
 #pragma unroll
@@ -364,13 +378,15 @@ extern "C" size_t gcs_gabor_workspace_bytes(int B, int H, int W, int n_scales) {
 }
 
 extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const int8_t *packed,
-                                  const int32_t *bias, int n_scales, int n_orient, int shift, void *workspace,
+                                  const int32_t *bias, int n_scales, int n_orient, int ksize, int shift, void *workspace,
                                   uint16_t *feats, gcs_stream_t stream) {
     if (!img || !packed || !bias || !feats || !workspace)
         return gcs_fail(GCS_EINVAL, "gcs_gabor_features: NULL pointer");
     if (B <= 0) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: B must be > 0");
     if (H < 8 || W < 8) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H and W must be >= 8");
     if (shift < 0 || shift > 23) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: shift out of range");
+    if (ksize < 1 || ksize > GCS_KSIZE_MAX || (ksize & 1) == 0)
+        return gcs_fail(GCS_EINVAL, "gcs_gabor_features: ksize must be odd and <= 15");
     if (B > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: B too large for one launch");
     GcsLayout lo;
     if (!gcs_make_layout(H, W, n_scales, n_orient, &lo))
@@ -415,10 +431,17 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
             const int8_t *ap = packed + (size_t)(mt_base + mt0) * 8 * 64 * 16;
             const int32_t *bp = bias + (size_t)(mt_base + mt0) * 8;
-#define GCS_GABOR_LAUNCH(MT_, GL_)                                                                                 \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp, lo.FL[L], \
-                       8 * mt0, shift, reinterpret_cast<unsigned char *>(feats), pitchL, tiles_x, tiles_per_image,          \
-                       total_tiles, L, lo.bx_n, lo.ntiles, lo.tile_bytes, lo.off[L])
+#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_, SH_)                                                                            \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_, SH_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp,        \
+                       lo.FL[L], 8 * mt0, shift, reinterpret_cast<unsigned char *>(feats), pitchL, tiles_x,               \
+                       tiles_per_image, total_tiles, L, lo.bx_n, lo.ntiles, lo.tile_bytes, lo.off[L])
+            // fast epilogue needs shift == 8 (every Q15 bank); 7 K-steps need the kernel inside rows 1..13 of the frame
+#define GCS_GABOR_LAUNCH(MT_, GL_)                                       \
+    do {                                                                 \
+        if (shift != 8) GCS_GABOR_LAUNCH3(MT_, GL_, 8, false);           \
+        else if (ksize <= 13) GCS_GABOR_LAUNCH3(MT_, GL_, 7, true);      \
+        else GCS_GABOR_LAUNCH3(MT_, GL_, 8, true);                       \
+    } while (0)
             if (n == 2) {
                 switch (glast) {
                 case 1: GCS_GABOR_LAUNCH(2, 1); break;
@@ -434,6 +457,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 default: GCS_GABOR_LAUNCH(1, 4); break;
                 }
             }
+#undef GCS_GABOR_LAUNCH3
 #undef GCS_GABOR_LAUNCH
             GCS_CHECK_LAUNCH("gcs_gabor_features");
         }

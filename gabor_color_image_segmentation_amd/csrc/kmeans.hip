@@ -243,9 +243,9 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
-    // compact coarse levels of one tile: at most (D - D_0) * 128 bytes with D - D_0 <= D / 2 ... all of D when the
-    // bank has a single scale per level pair; sized for the worst case of the bucket
-    constexpr int KP_COARSE = DSTEPS == KP_DSTEPS_NARROW ? 40 * 128 : 104 * 128;
+    // compact copy of pyramid levels >= 2 of one tile (level 1 is replicated straight from the staging registers):
+    // at most (D / 2) * 32 bytes plus 16-byte padding per level; sized for the worst case of the bucket
+    constexpr int KP_COARSE = DSTEPS == KP_DSTEPS_NARROW ? 40 * 32 + 64 : 104 * 32 + 64;
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[KP_ROWS * KP_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_coarse[KP_COARSE];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
@@ -322,51 +322,83 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
 
     // ---- staging: the tile is ONE contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
-    //      ci = tid + 256*i is 16 bytes at byte 16*ci: level-0 chunks (the first 32*D_0) go to plane row ci>>5,
-    //      pixels 8*(ci&31).. ; the rest is the compact coarse levels and goes to s_coarse untouched.
-    //      Loads and LDS writes are UNCONDITIONAL: a per-chunk guard makes hipcc branch around every
+    //      ci = tid + 256*i is 16 bytes at byte 16*ci:
+    //        level-0 chunks (the first 32*D_0) are 8 pixels of plane row ci>>5: copied as they are;
+    //        level-1 chunks (the next 8*D_1) are 2 rows x 4 pixels of one block's 4x4 parents: each row is replicated
+    //          into two fine rows of 8 pixels, i.e. 64 contiguous bytes of the plane row, straight from the registers
+    //          (SPEC.md §3: feat[y][x] = g_L[y >> L][x >> L]);
+    //        the rest (levels >= 2: deep banks only) goes to s_coarse untouched and is replicated by expand_deep().
+    //      Loads and LDS writes are UNCONDITIONAL per wave: a per-chunk guard makes hipcc branch around every
     //      load / write with exec masking and drain vmcnt(0) before each write. Chunks beyond the tile
     //      are clamped to its last chunk: they re-read and re-write it with its own data.
     const int n0 = 32 * lo.DL[0];                      // level-0 chunks
+    const int n1 = lo.n_levels > 1 ? 8 * lo.DL[1] : 0; // level-1 chunks
     const int nchunk = lo.tile_bytes >> 4;
     v4i st[NST];
     int sdst[NST], ssrc[NST];
+    int scls[NST];                                     // wave-uniform: 0 = every lane copies, 1 = every lane replicates, 2 = mixed
+    bool sl1[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int ci = min(tid + KP_TP * i, nchunk - 1);
         ssrc[i] = ci;
+        const int c1 = ci - n0;
+        const bool l1 = c1 >= 0 && c1 < n1;
+        sl1[i] = l1;
         sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
-                          : (int)(size_t)&s_coarse[(ci - n0) * 16];
+                  : l1    ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 3)) * KP_PITCH + (c1 & 7) * 64]
+                          : (int)(size_t)&s_coarse[(c1 - n1) * 16];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(l1);
+        scls[i] = m == 0ull ? 0 : m == ~0ull ? 1 : 2;
     }
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
         for (int i = 0; i < NST; ++i) st[i] = src[ssrc[i]];
     };
+    typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
-            *reinterpret_cast<__attribute__((address_space(3))) v4i *>(sdst[i]) = st[i];
+        for (int i = 0; i < NST; ++i) {
+            const v4i v = st[i];
+            if (scls[i] == 0) {
+                *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
+            } else {
+                // coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice
+                v4i ra, rb;
+                ra[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x01000100u);
+                ra[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x03020302u);
+                ra[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x01000100u);
+                ra[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x03020302u);
+                rb[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[2], 0x01000100u);
+                rb[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[2], 0x03020302u);
+                rb[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[3], 0x01000100u);
+                rb[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[3], 0x03020302u);
+                if (scls[i] == 1) {
+                    lds_v4i_ptr d = reinterpret_cast<lds_v4i_ptr>(sdst[i]);
+                    d[0] = ra; d[1] = ra; d[2] = rb; d[3] = rb;
+                } else if (sl1[i]) {                      // a wave whose chunks straddle a level boundary
+                    lds_v4i_ptr d = reinterpret_cast<lds_v4i_ptr>(sdst[i]);
+                    d[0] = ra; d[1] = ra; d[2] = rb; d[3] = rb;
+                } else {
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
+                }
+            }
+        }
     };
-    // Coarse levels: every group of 8 consecutive pixels of a plane row (one row of one 8x8 block) is the
-    // replication of 8 >> L level-L pixels of the compact copy (SPEC.md §3: feat[y][x] = g_L[y >> L][x >> L]).
-    auto expand_coarse = [&]() {
-        for (int L = 1; L < lo.n_levels; ++L) {
+    // Levels >= 2 (deep banks): every group of 8 consecutive pixels of a plane row (one row of one 8x8 block) is the
+    // replication of 8 >> L level-L pixels of the compact copy in s_coarse.
+    auto expand_deep = [&]() {
+        for (int L = 2; L < lo.n_levels; ++L) {
             const int side = 8 >> L;                              // level-L pixels per block side
-            const unsigned char *srcL = s_coarse + (lo.off[L] - lo.off[1]);
+            const unsigned char *srcL = s_coarse + (lo.off[L] - lo.off[2]);
             const int items = lo.DL[L] * 32;                      // (plane, block in tile, fine row)
             for (int it = tid; it < items; it += KP_TP) {
                 const int rr = it >> 5, grp = it & 31;
                 const int blkq = grp >> 3, iy = grp & 7;
                 const unsigned char *s = srcL + (((rr * 4 + blkq) * side + (iy >> L)) * side) * 2;
                 v4i o;
-                if (L == 1) {
-                    const v2i v = *reinterpret_cast<const v2i *>(s);          // 4 pixels
-                    o[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x01000100u);
-                    o[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x03020302u);
-                    o[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x01000100u);
-                    o[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x03020302u);
-                } else if (L == 2) {
+                if (L == 2) {
                     const unsigned v = *reinterpret_cast<const unsigned *>(s);  // 2 pixels
                     o[0] = o[1] = (int)__builtin_amdgcn_perm(0u, v, 0x01000100u);
                     o[2] = o[3] = (int)__builtin_amdgcn_perm(0u, v, 0x03020302u);
@@ -390,6 +422,16 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     auto phys = [&](int lt) { return reverse ? ntiles - 1 - lt : lt; };
     int ltile = part;
     if (ltile < ntiles) stage_load(phys(ltile));
+    // this wave's block (one 8x8 block per wave) as (block row, block column), advanced by 4 * parts blocks per step
+    // without a division: which pixels exist and vote is decided from it
+    const int bstep = 4 * parts;
+    const int step_q = __builtin_amdgcn_readfirstlane(bstep / lo.bx_n), step_r = bstep - step_q * lo.bx_n;
+    int by, bx;
+    {
+        const int blk0 = __builtin_amdgcn_readfirstlane(4 * phys(part < ntiles ? part : 0) + wave);
+        by = blk0 / lo.bx_n;
+        bx = blk0 - by * lo.bx_n;
+    }
     for (; ltile < ntiles; ltile += parts) {
         const int tile = phys(ltile);
         stage_write();
@@ -399,14 +441,12 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
         __builtin_amdgcn_s_setprio(3);
         if (ltile + parts < ntiles) stage_load(phys(ltile + parts));   // in flight during the MFMAs
         __builtin_amdgcn_s_setprio(0);
-        if (lo.n_levels > 1) {
-            expand_coarse();
+        if (lo.n_levels > 2) {
+            expand_deep();
             __syncthreads();
         }
 
-        // this wave's block (one 8x8 block per wave): which pixels exist and vote
-        const int blk = __builtin_amdgcn_readfirstlane(4 * tile + wave);
-        const int by = blk / lo.bx_n, bx = blk - by * lo.bx_n;
+        const int blk = 4 * tile + wave;
         // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -497,6 +537,15 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
                 bx_[3] = (int)__builtin_amdgcn_perm((unsigned)w1[3], (unsigned)w1[2], usel);
                 accu[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[nt], 0, 0, 0);
             }
+        }
+        if (reverse) {                                           // next block of this wave: 4 * parts blocks back / on
+            bx -= step_r;
+            by -= step_q;
+            if (bx < 0) { bx += lo.bx_n; --by; }
+        } else {
+            bx += step_r;
+            by += step_q;
+            if (bx >= lo.bx_n) { bx -= lo.bx_n; ++by; }
         }
         __syncthreads();
     }

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 11
+#define GCS_ABI_VERSION 12
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_SCALES_MAX 8  /* octave pyramid of at most 4 levels: scales 2L, 2L+1 run on level L (SPEC.md §2) */
@@ -71,10 +71,11 @@ size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 size_t gcs_gabor_workspace_bytes(int B, int H, int W, int n_scales);
 
 /* SPEC.md §3: img_dev [B][H][W][3] uint8 -> feats_dev slab (pyramid + filter bank + magnitude).
- * Fills the slot's first stage (script.py:30). Requires H, W >= 8. workspace_dev:
+ * Fills the slot's first stage (script.py:30). Requires H, W >= 8; ksize and shift are those of the packed bank
+ * (ksize <= 13 and shift == 8, i.e. every default-style Q15 bank, take the shorter kernels). workspace_dev:
  * gcs_gabor_workspace_bytes() bytes of device scratch, contents undefined before and after. */
 int gcs_gabor_features(const uint8_t *img_dev, int B, int H, int W, const int8_t *packed_dev,
-                       const int32_t *bias_dev, int n_scales, int n_orient, int shift, void *workspace_dev,
+                       const int32_t *bias_dev, int n_scales, int n_orient, int ksize, int shift, void *workspace_dev,
                        uint16_t *feats_dev, gcs_stream_t stream);
 
 /* Slab -> canonical [B][D][H][W] uint16 (level-L responses replicated over 2^L blocks; tests / debugging). */

@@ -10,11 +10,25 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 
+def _default_threads():
+    """Affinity mask cut down to the cgroup CPU quota: one OpenMP thread per core this process may really use."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def load():
     global _lib
     if _lib is None:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])       # no-op when up to date
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")              # idle threads sleep: CPU shares are common
         _lib = C.CDLL(_SO)
+        _lib.oracle_set_threads(_default_threads())
     return _lib
 
 

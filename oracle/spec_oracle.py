@@ -28,7 +28,7 @@ _CROSS3 = ndi.generate_binary_structure(2, 1)
 
 
 # --------------------------------------------------------------------------- bank
-def bank(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0), bandwidth=1.0):
+def bank(n_scales=4, n_orient=6, ksize=13, f_max=0.4, ratio=math.sqrt(2.0), bandwidth=1.0):
     """SPEC.md §2. Returns (tapq int64 [F,2,ks,ks], shift)."""
     r = (ksize - 1) // 2
     ax = np.arange(-r, r + 1, dtype=np.float64)
@@ -46,7 +46,7 @@ def bank(n_scales=4, n_orient=6, ksize=15, f_max=0.4, ratio=math.sqrt(2.0), band
             phase = 2.0 * math.pi * freq * (dx * math.cos(theta) + dy * math.sin(theta))
             taps.append(np.stack([env * np.cos(phase), env * np.sin(phase)]))
     taps = np.stack(taps)
-    e = int(math.floor(math.log2(32639.0 / np.abs(taps).max())))
+    e = min(15, int(math.floor(math.log2(32639.0 / np.abs(taps).max()))))
     tapq = np.rint(taps * 2.0 ** e).astype(np.int64)
     return tapq, e - 7
 
@@ -161,7 +161,7 @@ def kmeans(x: np.ndarray, k: int, n_iter: int, init_from: np.ndarray | None = No
 
 
 # ------------------------------------------------------------------------ segment
-def segment(img, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=15, f_max=0.4,
+def segment(img, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=13, f_max=0.4,
             ratio=math.sqrt(2.0), bandwidth=1.0, return_all=False):
     """segment(image) -> (H,W) int32 label map (per-image codebook)."""
     tapq, shift = bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)

@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 11
+    assert lib.gcs_abi_version() == 12
 
 
 def test_no_torch_types_in_the_abi():
@@ -116,10 +116,10 @@ def test_bank_pack_rejects_bad_input(lib):
 def test_device_entry_points_validate_before_launching(lib):
     """Argument errors are reported without touching the GPU (so this runs on the CPU box)."""
     one = C.c_void_p(16)                                   # non-NULL dummy, never dereferenced
-    assert lib.gcs_gabor_features(None, 1, 16, 16, one, one, 4, 6, 11, one, one, None) == 1
-    assert lib.gcs_gabor_features(one, 1, 7, 16, one, one, 4, 6, 11, one, one, None) == 1      # H < 8
-    assert lib.gcs_gabor_features(one, 0, 16, 16, one, one, 4, 6, 11, one, one, None) == 1
-    assert lib.gcs_gabor_features(one, 1, 16, 16, one, one, 9, 6, 11, one, one, None) == 1     # more than 4 pyramid levels
+    assert lib.gcs_gabor_features(None, 1, 16, 16, one, one, 4, 6, 13, 8, one, one, None) == 1
+    assert lib.gcs_gabor_features(one, 1, 7, 16, one, one, 4, 6, 13, 8, one, one, None) == 1      # H < 8
+    assert lib.gcs_gabor_features(one, 0, 16, 16, one, one, 4, 6, 13, 8, one, one, None) == 1
+    assert lib.gcs_gabor_features(one, 1, 16, 16, one, one, 9, 6, 13, 8, one, one, None) == 1     # more than 4 pyramid levels
     assert lib.gcs_kmeans_init(one, 2, 16, 16, 4, 6, 17, 2, one, None) == 1             # k > 16
     assert lib.gcs_kmeans_init(one, 4, 16, 16, 4, 6, 8, 3, one, None) == 1              # n_sets not in {1,B}
     assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 0, 1, 0, 16, 0, one, one, None) == 1

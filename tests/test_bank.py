@@ -10,12 +10,16 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def test_default_bank_shape_and_exponent():
     b = make_bank()
-    assert b.tapq.shape == (24, 2, 15, 15) and b.tapq.dtype == np.int16
+    assert b.tapq.shape == (24, 2, 13, 13) and b.tapq.dtype == np.int16
     assert b.n_filters == 24 and b.n_features == 72
-    assert b.shift == b.exponent - 7 and b.shift >= 0
+    assert b.exponent == 15 and b.shift == 8                   # Q15 taps: the Q7 response is bytes 1..2 of v (SPEC.md §2)
     assert np.abs(b.tapq).max() <= 32639
-    # the exponent is maximal: one more bit would overflow the two-digit range
-    assert np.abs(gabor_taps()).max() * 2.0 ** (b.exponent + 1) > 32639
+    # a kernel so peaked that Q15 would not fit two byte digits gets the largest exponent that does
+    one = make_bank(1, 1, 1)
+    assert one.exponent == 14 and int(one.tapq[0, 0, 0, 0]) == 16384
+    # responses fit int16 after the shift (the packed epilogue relies on it) and their squares' sum fits int32
+    amax = (255 * np.abs(b.tapq.astype(np.int64)).sum(axis=(2, 3)).max()) >> b.shift
+    assert amax <= 32767 and 2 * amax * amax < 2 ** 31
 
 
 def test_bank_matches_oracle_and_golden():
@@ -34,17 +38,17 @@ def test_float_taps_are_the_scikit_image_gabor_kernel(name, ns, no):
     instead of skimage's 1/(2 pi sigma^2)), and both oracle and product share it."""
     import math
     z = np.load(os.path.join(GOLD, "bank_skimage.npz"))
-    ref = z[name][:, 8:23, 8:23]                                   # central 15x15 of the 31x31 frame
+    ref = z[name][:, 9:22, 9:22]                                   # central 13x13 of the 31x31 frame
     taps = gabor_taps(n_scales=ns, n_orient=no)
     kappa = math.sqrt(math.log(2.0) / 2.0) / math.pi * 3.0
-    dy, dx = np.mgrid[-7:8, -7:8]
+    dy, dx = np.mgrid[-6:7, -6:7]
     for f in range(ns * no):
         s_ = f // no
         sigma = kappa / (0.4 / math.sqrt(2.0) ** s_ * 2.0 ** (s_ // 2))        # f_base of pyramid level s // 2
         gain = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma)).sum() / (2.0 * math.pi * sigma * sigma)
         mine = (taps[f, 0] + 1j * taps[f, 1]) * gain
         support = np.abs(ref[f]) > 0                               # skimage truncates at 3 sigma
-        assert support.sum() >= 49 and not support[[0, -1]].any() and not support[:, [0, -1]].any()   # inside the 15x15 frame
+        assert support.sum() >= 49 and np.count_nonzero(z[name][f]) == support.sum()         # skimage's support lies inside 13x13
         assert np.abs(mine - ref[f])[support].max() < 1e-15
         # the quantised bank the kernels run is that kernel to within half an LSB
         b = make_bank(n_scales=ns, n_orient=no)

@@ -8,11 +8,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $R/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-other-mode > $OUT/bench_trace.log 2>&1
 grep '"metric"' $OUT/bench_trace.log > $R/gpurun_out/profiles/${TAG}_bench_under_rocprof.json || true
 cp $OUT/trace/*/*kernel_stats.csv $R/gpurun_out/profiles/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > $OUT/bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-other-mode > $OUT/bench_$c.log 2>&1
 done
 python $R/tools/hbm_traffic.py $OUT $R/gpurun_out/profiles/${TAG}_hbm_traffic.json
 cp $R/gpurun_out/profiles/${TAG}_hbm_traffic.json $R/gpurun_out/profiles/hbm_traffic_latest.json
