@@ -27,22 +27,20 @@ __device__ __forceinline__ int reflect(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
-// floor(sqrt(n)) for n < 2^31 (SPEC.md §3 bound: n <= 2 * 32724^2), exact, in 6 VALU ops:
+// floor(sqrt(n)) for n < 2^31 (SPEC.md §3 bound: n <= 2 * 32724^2), exact, in 7 VALU ops:
 //   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
 //   bits = r + 2^23 (as uint)          the sum has ulp 1: bits = 0x4B000000 + RNE(r), RNE(r) in {floor(s), floor(s)+1}
 //   qr^2 = v_mul_u32_u24(bits, bits)   the multiplier only sees the low 24 bits, i.e. qr = RNE(r) (< 2^16)
-//   q    = qr - (qr^2 > n)             v_cmp_gt_u32 + ONE v_subbrev_co_u32: bits - 0x4B000000 - carry
-// (v_cvt_f32_u32, v_sqrt_f32, v_add_f32, v_mul_u32_u24, v_cmp_gt_u32, v_subbrev_co_u32.) In this kernel every VALU
-// instruction costs ~4.2 cycles whatever its kind (PMC, profiles/r1_notes.md), so the count is what matters.
+//   q    = qr - (qr^2 > n)             sign arithmetic, one v_add3: bits - 0x4B000000 + ((int)(n - qr^2) >> 31);
+//                                      qr <= 46341 so qr^2 < 2^31 + 2^17 and the signed difference cannot overflow.
+// Plain C on purpose (no inline asm): an asm statement's VGPR writes are invisible to hipcc's hazard recognizer, and once
+// the epilogue is interleaved with a running MFMA chain an asm result can be allocated to a dead accumulator lane that
+// the matrix pipe is still about to write (write-after-write: wrong pixels; found the hard way in round 2).
 // Exhaustively checked over [0, 2^31) by tests/test_gpu_parity.py::test_isqrt31_exhaustive.
 __device__ __forceinline__ unsigned isqrt31(unsigned n) {
     const unsigned bits = __float_as_uint(__builtin_amdgcn_sqrtf((float)n) + 8388608.0f);
-    const unsigned sq = __umul24(bits, bits);
-    unsigned q;
-    // (the magic constant sits in a VGPR: a literal and the carry-in would both need the constant bus)
-    asm("v_cmp_gt_u32 vcc, %1, %2\n\tv_subbrev_co_u32 %0, vcc, %4, %3, vcc"
-        : "=v"(q) : "v"(sq), "v"(n), "v"(bits), "v"(0x4B000000u) : "vcc");
-    return q;
+    const int d = (int)(n - __umul24(bits, bits));
+    return bits - 0x4B000000u + (unsigned)(d >> 31);
 }
 
 // out[i] = 1 if isqrt31 is wrong anywhere in [i * chunk, (i+1) * chunk) ∩ [0, n_max] (test hook; SPEC.md §3 domain)
@@ -135,15 +133,16 @@ __global__ __launch_bounds__(256) void gabor_down_pad_kernel(const uint8_t *__re
 #ifndef GCS_GABOR_WAVES
 #define GCS_GABOR_WAVES 2
 #endif
-constexpr int GCS_GABOR_MTMAX = 2;   // row tiles per launch: 3 needs ~250 VGPRs at 2 waves/SIMD and spills (measured slower)
+#ifndef GCS_GABOR_MTMAX_
+#define GCS_GABOR_MTMAX_ 2
+#endif
+constexpr int GCS_GABOR_MTMAX = GCS_GABOR_MTMAX_;   // row tiles per launch
 
 // One pyramid level. MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that
 // exist in the last row tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
 // KS = K-steps of 2 tap rows: 8 for a 15-row frame, 7 when ksize <= 13 (its rows 1..13 of the frame: the last K-step
-// would multiply zeros). SH8: shift == 8 (Q15 taps, SPEC.md §2): the Q7 response is bytes 1..2 of v, so ONE byte permute
-// packs (a_re, a_im) as int16 pairs and ONE v_dot2_i32_i16 gives re^2 + im^2 (|a| <= 32724 fits int16).
-typedef short v2s __attribute__((ext_vector_type(2)));
-template <int MT, int GLAST, int KS, bool SH8>
+// would multiply zeros).
+template <int MT, int GLAST, int KS>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int8_t *__restrict__ planes, int HL, int Hp, int Wp, const int8_t *__restrict__ apack,
     const int32_t *__restrict__ bias, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int pitchL,
@@ -193,6 +192,8 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int r = lane & 31, h = lane >> 5;
     const int li = r & 7, lyy = r >> 3;
 
+    int k256 = 256, k65536 = 65536;
+    asm volatile("" : "+s"(k256), "+s"(k65536));      // opaque multipliers: keep v_mad_i32_i24 / v_mad_u32_u24, not shifts
     int bias_v[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -218,77 +219,79 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             if (y0 + wave * 8 + rb * 4 >= HL) break;   // block wholly below the image (H = 321: 1 row in the last tile row)
             const int trow = wave * 8 + rb * 4 + lyy;
             unsigned outp[MT][4][4];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                // window: 8 tap rows (this half-wave's parity) x 20 bytes starting at 8*li + 4*qq
-                int win[KS][5];
+            // The 8 pixel shifts s = 4*qq + t of this 4-row block. Step s runs its MFMA chain into one of two accumulator
+            // sets and the epilogue of step s-1 reads the other one, both inside one scheduling region, so hipcc can start
+            // the next chain before the previous step's magnitudes are finished (the matrix results it needs are long
+            // complete: no s_nop wait on the fresh chain). Forcing a fixed VALU/MFMA interleave with sched_group_barrier
+            // on top of this was slower (same-box A/B: 0.596 vs 0.569 ms per 64 images; profiles/r2_notes.md).
+            v16i acc[2][MT];
+            int win[KS][5];
+            auto load_window = [&](int qq) {
+                // 2*KS tap rows of this half-wave's parity x 20 bytes starting at 8*li + 4*qq
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     const int *rp = reinterpret_cast<const int *>(&s_tile[buf][c][trow + 2 * kk + h][8 * li + 4 * qq]);
 #pragma unroll
                     for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
                 }
+            };
+            auto epilogue = [&](const v16i (&ac)[MT], int qq, int t) {
+                // rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter
+                unsigned mag[MT][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    v16i acc[MT];
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (mt == MT - 1 && g >= GLAST) continue;
+                        // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22); the factor sits in an SGPR the
+                        // compiler cannot see through, or it turns the multiply into a left shift (2.3x slower here)
+                        const int v_re = __mul24(ac[mt][4 * g + 1], k256) + ac[mt][4 * g + 0] + bias_v[mt][g];
+                        const int v_im = __mul24(ac[mt][4 * g + 3], k256) + ac[mt][4 * g + 2];
+                        const int a_re = v_re >> shift, a_im = v_im >> shift;
+                        const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                        mag[mt][g] = isqrt31(n);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (mt == MT - 1 && g >= GLAST) continue;
+                        unsigned &o = outp[mt][g][2 * qq + (t >> 1)];
+                        if ((t & 1) == 0)
+                            o = mag[mt][g];
+                        else
+                            o = __umul24(mag[mt][g], k65536) + o;      // pack the odd pixel into the high half
+                        // materialise now: otherwise hipcc sinks the whole epilogue into the
+                        // store branches and keeps every accumulator live until then
+                        asm volatile("" : "+v"(o));
+                    }
+            };
+            load_window(0);
+#pragma unroll
+            for (int st = 0; st <= 8; ++st) {
+                const int qq = st >> 2, t = st & 3;
+                if (st < 8) {
+                    if (st == 4) load_window(1);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[mt][e] = 0;   // inline-constant C of the first MFMA
-                    // the wave inside its MFMA chain outranks the one in its (pure VALU) epilogue: -2.5 % (A/B)
-                    __builtin_amdgcn_s_setprio(1);
+                        for (int e = 0; e < 16; ++e) acc[st & 1][mt][e] = 0;   // inline-constant C of the first MFMA
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk) {
                         // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
                         v4i bf;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            bf[j] = (t == 0) ? win[kk][j]       // v_alignbit_b32: same result as v_alignbyte, 2.4x the rate
+                            bf[j] = (t == 0) ? win[kk][j]
                                              : (int)__builtin_amdgcn_alignbit((unsigned)win[kk][j + 1],
                                                                               (unsigned)win[kk][j], 8 * t);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[mt], 0, 0, 0);
+                            acc[st & 1][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[st & 1][mt], 0, 0, 0);
                     }
-                    __builtin_amdgcn_s_setprio(0);
-                    // epilogue: rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter.
-                    // All magnitudes are computed as independent chains (ILP), then pinned.
-                    unsigned mag[MT][4];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (mt == MT - 1 && g >= GLAST) continue;
-                            // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22), not a shift (slow here)
-                            const int v_re = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g + 0] + bias_v[mt][g];
-                            const int v_im = __mul24(acc[mt][4 * g + 3], 256) + acc[mt][4 * g + 2];
-                            unsigned n;
-                            if (SH8) {
-                                const unsigned pk = __builtin_amdgcn_perm((unsigned)v_re, (unsigned)v_im, 0x06050201u);
-                                n = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk), __builtin_bit_cast(v2s, pk), 0, false);
-                            } else {
-                                const int a_re = v_re >> shift, a_im = v_im >> shift;
-                                n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
-                            }
-                            mag[mt][g] = isqrt31(n);
-                        }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (mt == MT - 1 && g >= GLAST) continue;
-                            unsigned &o = outp[mt][g][2 * qq + (t >> 1)];
-                            if ((t & 1) == 0)
-                                o = mag[mt][g];
-                            else
-                                o = __umul24(mag[mt][g], 65536u) + o;      // pack the odd pixel into the high half
-                            // materialise now: otherwise hipcc sinks the whole epilogue into the
-                            // store branches and keeps every accumulator live until then
-                            asm volatile("" : "+v"(o));
-                        }
-                    // keep hipcc from building all four shifts' fragments up front
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (st > 0) epilogue(acc[(st - 1) & 1], (st - 1) >> 2, (st - 1) & 3);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy. Level 0: one row of one 8x8 block = one 16-byte
             // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels).
@@ -431,16 +434,15 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
             const int8_t *ap = packed + (size_t)(mt_base + mt0) * 8 * 64 * 16;
             const int32_t *bp = bias + (size_t)(mt_base + mt0) * 8;
-#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_, SH_)                                                                            \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_, SH_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp,        \
+#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_)                                                                                 \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp,        \
                        lo.FL[L], 8 * mt0, shift, reinterpret_cast<unsigned char *>(feats), pitchL, tiles_x,               \
                        tiles_per_image, total_tiles, L, lo.bx_n, lo.ntiles, lo.tile_bytes, lo.off[L])
-            // fast epilogue needs shift == 8 (every Q15 bank); 7 K-steps need the kernel inside rows 1..13 of the frame
-#define GCS_GABOR_LAUNCH(MT_, GL_)                                       \
-    do {                                                                 \
-        if (shift != 8) GCS_GABOR_LAUNCH3(MT_, GL_, 8, false);           \
-        else if (ksize <= 13) GCS_GABOR_LAUNCH3(MT_, GL_, 7, true);      \
-        else GCS_GABOR_LAUNCH3(MT_, GL_, 8, true);                       \
+            // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
+#define GCS_GABOR_LAUNCH(MT_, GL_)                                   \
+    do {                                                             \
+        if (ksize <= 13) GCS_GABOR_LAUNCH3(MT_, GL_, 7);             \
+        else GCS_GABOR_LAUNCH3(MT_, GL_, 8);                         \
     } while (0)
             if (n == 2) {
                 switch (glast) {

@@ -184,8 +184,9 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
                         src=dist.get_global_rank(dist_group, 0) if dist_group is not None else 0,
                         group=dist_group)
     for t in range(n_iter):
-        # alternate the sweep direction: a pass starts where the previous one ended (Infinity Cache reuse)
-        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows, reverse=bool(t & 1) and not _NO_REVERSE)
+        # alternate the sweep direction: a pass starts where the previous one ended (Infinity Cache reuse); the first
+        # pass runs back to front because the Gabor stage, which has just written the slab, finished at its end
+        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows, reverse=not (t & 1) and not _NO_REVERSE)
         if t < n_iter - 1:
             if dist is None:
                 ops.reduce_finalize(partials, b, h, w, k, n_sets, sums, cent)

@@ -158,3 +158,58 @@ def test_rccl_carries_the_collective_dtypes(tmp_path, built):
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / "rccl_ok").read() == "1"
+
+
+def _global_hip_worker(rank, world, port, per_rank, height, width, n_iter, k, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+    imgs = synthetic_shard(rank * per_rank, per_rank, height, width, seed=0)      # this rank's shard of the global batch
+    seg = Segmenter(k=k, n_iter=n_iter, device="cuda:0")
+    out = seg.segment_device(torch.from_numpy(imgs).cuda(), mode="global").cpu().numpy()
+    np.save(os.path.join(tmp, f"glabels_{rank}.npy"), out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,per_rank", [(2, 3), (3, 2)])
+def test_global_codebook_hip_ranks_equal_unsharded_c_oracle(tmp_path, built, world, per_rank):
+    """BASELINE config 3 in miniature, through the HIP kernels: `world` processes share cuda:0, each owns `per_rank` images
+    of one global batch (bench.py's sharding: synthetic_shard), rank 0 broadcasts the init centroids, every Lloyd pass
+    all-reduces the int64 sums (gloo carries the collectives here, RCCL on a multi-GPU node). The concatenated label maps
+    must equal the C oracle's global-codebook result on the unsharded batch, pixel for pixel."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+    from oracle import c_oracle as co, spec_oracle as so
+    port = 36500 + (os.getpid() % 2000) + world
+    height, width, n_iter, k = 136, 200, 6, 8
+    mp.spawn(_global_hip_worker, args=(world, port, per_rank, height, width, n_iter, k, str(tmp_path)), nprocs=world,
+             join=True)
+    got = np.concatenate([np.load(tmp_path / f"glabels_{r}.npy") for r in range(world)])
+    tapq, shift = so.bank()
+    ref = co.segment_batch(synthetic_shard(0, world * per_rank, height, width, seed=0), tapq, shift, 6, k=k, n_iter=n_iter,
+                           mode="global")
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_it(tmp_path, built):
+    """`python -m torch.distributed.run ... bench.py --gpus 2` exactly as the driver starts the N > 1 runs (one fresh
+    subprocess per rank; both ranks land on cuda:0 here and gloo stands in for RCCL): one JSON line from rank 0 with
+    n_gpus = 2 and a global batch of 2 x 64 images."""
+    import json
+    import subprocess
+    port = 37500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--spinup-steps", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert d["value"] > 0 and np.isfinite(d["value"]) and d["steps"] == 2
+    assert d["config"]["codebook"] == "global" and "all-reduce" in d["config"]["parallelism"]
