@@ -43,6 +43,9 @@ SIGNATURES = {
     "gcs_boundary_scratch_bytes": (_sz, [_i, _i, _i]),
     "gcs_boundary_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_region_counts": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gcs_boundary_batch_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "gcs_boundary_counts_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_region_counts_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gcs_connected_scratch_bytes": (_sz, [_i, _i, _i]),
     "gcs_connected_regions": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
 }

@@ -3,8 +3,8 @@
 // The reference ships no code for this path; slot: /root/reference/BSD_metrics/script.py:30.
 //
 // Kernels
-//   gabor_pad_kernel        level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised.
-//   gabor_down_pad_kernel   level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
+//   gabor_plane_kernel      level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised;
+//                           level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
 //                           padded plane of level L and, when a further level follows, as a compact image.
 //   gabor_mfma_kernel       one pyramid level: A = packed 2-digit int8 taps of the level's filters (rows = filter x
 //                           {re_lo,re_hi,im_lo,im_hi}, resident in registers), B = (pixel-128) windows built from an LDS
@@ -66,62 +66,92 @@ extern "C" int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_
     return GCS_OK;
 }
 
-// Level 0 pre-pass: interleaved uint8 RGB -> planar (pixel - 128) int8 with the reflect border and
-// the tile over-read already materialised: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128
-// for r < tiles_y*32 + 15, u < tiles_x*64 + 32. The main kernel then stages tiles with aligned
-// 16-byte copies and no index arithmetic. ~26 B of extra HBM traffic per pixel-channel row: noise.
-__global__ __launch_bounds__(256) void gabor_pad_kernel(const uint8_t *__restrict__ img, int H, int W, int Hp,
-                                                        int Wp, int8_t *__restrict__ planes) {
-    const int b = blockIdx.z, r = blockIdx.y;
-    const int gy = reflect(r - G_HALO, H);
-    const uint8_t *row = img + ((size_t)b * H + gy) * W * 3;
-    for (int u4 = blockIdx.x * blockDim.x + threadIdx.x; u4 < Wp / 4; u4 += gridDim.x * blockDim.x) {
-        unsigned o[3] = {0u, 0u, 0u};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int gx = reflect(4 * u4 + e - G_HALO, W);
-            const uint8_t *p = row + (size_t)gx * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c] |= (unsigned)(p[c] ^ 0x80) << (8 * e);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
-    }
+// Pre-passes. A thread produces 4 consecutive bytes of one padded plane row for the three channels:
+//   MODE 0  level 0: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128 (interleaved uint8 RGB -> planar int8 with
+//           the reflect border and the tile over-read materialised, so the main kernel stages tiles as aligned 16-byte
+//           copies with no index arithmetic);
+//   MODE 1  level 1 from the interleaved input, MODE 2 level L > 1 from the compact planar level L-1 image
+//           [B][3][Hs][Ws]: I_L[y][x] = (sum of the 2x2 block of I_{L-1}, indices clamped to the last row / column,
+//           + 2) >> 2 (SPEC.md §3 pyramid), evaluated at the reflected coordinates of the padded plane; `img_out` (may be
+//           NULL) receives the compact planar I_L for the next level.
+// Away from the borders the 4 pixels are 12 (MODE 0) or 2 x 24 (MODE 1) contiguous source bytes: they are fetched with
+// unaligned dword loads (gfx950 global memory takes any byte alignment) instead of one byte load per sample.
+typedef unsigned __attribute__((aligned(1))) unaligned_u32;
+
+__device__ __forceinline__ unsigned byte_of(const unsigned (&d)[6], int i) {   // byte i of a little-endian dword run
+    return (d[i >> 2] >> (8 * (i & 3))) & 255u;
 }
 
-// Level L >= 1 (SPEC.md §3 pyramid): I_L[y][x] = (sum of the 2x2 block of I_{L-1}, indices clamped to the last
-// row / column, + 2) >> 2, evaluated at the reflected coordinates of the padded plane. SRC_RGB: I_{L-1} is the
-// interleaved input image (L == 1), otherwise the compact planar level image [B][3][Hs][Ws] written by the previous
-// launch. `img_out` (may be NULL): compact planar I_L for the next level.
-template <bool SRC_RGB>
-__global__ __launch_bounds__(256) void gabor_down_pad_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL,
-                                                             int WL, int Hp, int Wp, int8_t *__restrict__ planes,
-                                                             uint8_t *__restrict__ img_out) {
-    const int b = blockIdx.z, r = blockIdx.y;
+template <int MODE>
+__global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
+                                                          int Hp, int Wp, int8_t *__restrict__ planes,
+                                                          uint8_t *__restrict__ img_out) {
+    const int b = blockIdx.z;
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);               // 4 plane rows per workgroup, 64 threads each
+    if (r >= Hp) return;
     const int ly = reflect(r - G_HALO, HL);
-    const int y0 = 2 * ly, y1 = min(2 * ly + 1, Hs - 1);
-    for (int u4 = blockIdx.x * blockDim.x + threadIdx.x; u4 < Wp / 4; u4 += gridDim.x * blockDim.x) {
+    const int y0 = MODE == 0 ? ly : 2 * ly, y1 = MODE == 0 ? ly : min(2 * ly + 1, Hs - 1);
+    const bool row_in = r >= G_HALO && r - G_HALO < HL;
+    for (int u4 = blockIdx.x * 64 + (threadIdx.x & 63); u4 < Wp / 4; u4 += gridDim.x * 64) {
         unsigned o[3] = {0u, 0u, 0u};
+        const int l0 = 4 * u4 - G_HALO;                              // level column of this thread's first byte
+        const bool interior = l0 >= 0 && l0 + 3 < WL && (MODE == 0 || 2 * (l0 + 3) + 1 < Ws);
+        if (MODE != 2 && interior) {
+            unsigned m[3][4];
+            if (MODE == 0) {
+                const uint8_t *p = src + (((size_t)b * Hs + y0) * Ws + l0) * 3;
+                unsigned d[6];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int u = 4 * u4 + e;
-            const int lx = reflect(u - G_HALO, WL);
-            const int x0 = 2 * lx, x1 = min(2 * lx + 1, Ws - 1);
+                for (int i = 0; i < 3; ++i) d[i] = *reinterpret_cast<const unaligned_u32 *>(p + 4 * i);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                unsigned s;
-                if (SRC_RGB) {
-                    const uint8_t *p0 = src + ((size_t)b * Hs + y0) * Ws * 3 + c, *p1 = src + ((size_t)b * Hs + y1) * Ws * 3 + c;
-                    s = p0[(size_t)x0 * 3] + p0[(size_t)x1 * 3] + p1[(size_t)x0 * 3] + p1[(size_t)x1 * 3];
-                } else {
-                    const uint8_t *p0 = src + (((size_t)b * 3 + c) * Hs + y0) * Ws, *p1 = src + (((size_t)b * 3 + c) * Hs + y1) * Ws;
-                    s = p0[x0] + p0[x1] + p1[x0] + p1[x1];
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) m[c][e] = byte_of(d, 3 * e + c);
+            } else {
+                const uint8_t *p0 = src + (((size_t)b * Hs + y0) * Ws + 2 * l0) * 3;
+                const uint8_t *p1 = src + (((size_t)b * Hs + y1) * Ws + 2 * l0) * 3;
+                unsigned d0[6], d1[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    d0[i] = *reinterpret_cast<const unaligned_u32 *>(p0 + 4 * i);
+                    d1[i] = *reinterpret_cast<const unaligned_u32 *>(p1 + 4 * i);
                 }
-                const unsigned m = (s + 2u) >> 2;
-                o[c] |= (m ^ 0x80u) << (8 * e);
-                if (img_out && r >= G_HALO && r - G_HALO < HL && u >= G_HALO && u - G_HALO < WL)
-                    img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (u - G_HALO)] = (uint8_t)m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        m[c][e] = (byte_of(d0, 6 * e + c) + byte_of(d0, 6 * e + 3 + c) + byte_of(d1, 6 * e + c) +
+                                   byte_of(d1, 6 * e + 3 + c) + 2u) >> 2;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    o[c] |= (m[c][e] ^ 0x80u) << (8 * e);
+                    if (MODE != 0 && img_out && row_in)
+                        img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (l0 + e)] = (uint8_t)m[c][e];
+                }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int u = 4 * u4 + e;
+                const int lx = reflect(u - G_HALO, WL);
+                const int x0 = MODE == 0 ? lx : 2 * lx, x1 = MODE == 0 ? lx : min(2 * lx + 1, Ws - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned m;
+                    if (MODE == 2) {
+                        const uint8_t *p0 = src + (((size_t)b * 3 + c) * Hs + y0) * Ws, *p1 = src + (((size_t)b * 3 + c) * Hs + y1) * Ws;
+                        m = (p0[x0] + p0[x1] + p1[x0] + p1[x1] + 2u) >> 2;
+                    } else {
+                        const uint8_t *p0 = src + ((size_t)b * Hs + y0) * Ws * 3 + c, *p1 = src + ((size_t)b * Hs + y1) * Ws * 3 + c;
+                        m = MODE == 0 ? p0[(size_t)x0 * 3]
+                                      : (p0[(size_t)x0 * 3] + p0[(size_t)x1 * 3] + p1[(size_t)x0 * 3] + p1[(size_t)x1 * 3] + 2u) >> 2;
+                    }
+                    o[c] |= (m ^ 0x80u) << (8 * e);
+                    if (MODE != 0 && img_out && row_in && u >= G_HALO && u - G_HALO < WL)
+                        img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (u - G_HALO)] = (uint8_t)m;
+                }
             }
         }
 #pragma unroll
@@ -396,26 +426,24 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         return gcs_fail(GCS_EINVAL, "gcs_gabor_features: need 1 <= n_scales <= 8, n_orient >= 1");
     if ((long long)B * lo.ntiles * lo.tile_bytes > 0x7fffffffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: slab too large");
     const GaborWs ws = gabor_ws(B, H, W, lo.n_levels);
-    if (ws.Hp[0] > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
+    if (ws.Hp[0] / 4 + 1 > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
     unsigned char *wsb = static_cast<unsigned char *>(workspace);
     const dim3 block(256);
     int mt_base = 0;
     for (int L = 0; L < lo.n_levels; ++L) {
         int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
         const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
-        const dim3 pgrid((Wp / 4 + 255) / 256, Hp, B);
-        if (L == 0) {
-            hipLaunchKernelGGL(gabor_pad_kernel, pgrid, block, 0, stream, img, H, W, Hp, Wp, planes);
-        } else {
-            uint8_t *img_out = L + 1 < lo.n_levels ? wsb + ws.img_off[L] : nullptr;
-            if (L == 1)
-                hipLaunchKernelGGL((gabor_down_pad_kernel<true>), pgrid, block, 0, stream, img, H, W, HL, WL, Hp, Wp,
-                                   planes, img_out);
-            else
-                hipLaunchKernelGGL((gabor_down_pad_kernel<false>), pgrid, block, 0, stream,
-                                   (const uint8_t *)(wsb + ws.img_off[L - 1]), ws.HL[L - 1], ws.WL[L - 1], HL, WL, Hp,
-                                   Wp, planes, img_out);
-        }
+        const dim3 pgrid((Wp / 4 + 63) / 64, (Hp + 3) / 4, B);
+        uint8_t *img_out = (L >= 1 && L + 1 < lo.n_levels) ? wsb + ws.img_off[L] : nullptr;
+        if (L == 0)
+            hipLaunchKernelGGL((gabor_plane_kernel<0>), pgrid, block, 0, stream, img, H, W, HL, WL, Hp, Wp, planes,
+                               (uint8_t *)nullptr);
+        else if (L == 1)
+            hipLaunchKernelGGL((gabor_plane_kernel<1>), pgrid, block, 0, stream, img, H, W, HL, WL, Hp, Wp, planes, img_out);
+        else
+            hipLaunchKernelGGL((gabor_plane_kernel<2>), pgrid, block, 0, stream,
+                               (const uint8_t *)(wsb + ws.img_off[L - 1]), ws.HL[L - 1], ws.WL[L - 1], HL, WL, Hp, Wp,
+                               planes, img_out);
         GCS_CHECK_LAUNCH("gcs_gabor_features(pad)");
         const int tiles_x = (WL + G_TW - 1) / G_TW, tiles_y = (HL + G_TH - 1) / G_TH;
         const int tiles_per_image = tiles_x * tiles_y;

@@ -20,14 +20,16 @@ __device__ __forceinline__ bool thick_boundary(const T *m, int H, int W, int y, 
     return u != c || d != c || l != c || r != c;   // max != min over {c,u,d,l,r}
 }
 
-// maps: plane 0 = boundaries of the label map, planes 1..A = boundaries of the annotator maps
-__global__ void boundary_maps_kernel(const int32_t *__restrict__ labels, const uint16_t *__restrict__ truth, int A,
+// Batched form: B label maps [B][H][W] and T annotator maps [T][H][W] (all annotators of all images, image after image);
+// img_of[t] = image of annotator t (NULL: every annotator belongs to image 0, the single-image call).
+// maps: planes 0..B-1 = boundaries of the label maps, planes B..B+T-1 = boundaries of the annotator maps
+__global__ void boundary_maps_kernel(const int32_t *__restrict__ labels, const uint16_t *__restrict__ truth, int B, int T,
                                      int H, int W, uint8_t *__restrict__ maps) {
-    const int n = H * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (A + 1) * n; i += gridDim.x * blockDim.x) {
-        const int a = i / n, p = i % n, y = p / W, x = p % W;
-        maps[i] = a == 0 ? thick_boundary(labels, H, W, y, x)
-                         : thick_boundary(truth + (size_t)(a - 1) * n, H, W, y, x);
+    const size_t n = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(B + T) * n; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i / n), p = (int)(i % n), y = p / W, x = p % W;
+        maps[i] = q < B ? thick_boundary(labels + (size_t)q * n, H, W, y, x)
+                        : thick_boundary(truth + (size_t)(q - B) * n, H, W, y, x);
     }
 }
 
@@ -43,20 +45,25 @@ __device__ __forceinline__ bool dilated5(const uint8_t *b, int H, int W, int y, 
     return false;
 }
 
-__global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, int A, int H, int W,
-                                       unsigned long long *__restrict__ counts) {
+// counts: [b] = sum bd(L_b) for b < B; then per annotator t: [B + 3t] = sum dil5(bd(L_b)) & bd(T_t)   (recall numerator),
+// [B + 3t + 1] = sum bd(T_t) (recall denominator), [B + 3t + 2] = sum bd(L_b) & dil5(bd(T_t)) (precision numerator),
+// b = img_of[t]. With B = 1 this is the single-image layout [1 + 3A].
+__global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, const int32_t *__restrict__ img_of, int B, int T,
+                                       int H, int W, unsigned long long *__restrict__ counts) {
     const int n = H * W;
-    const int a = blockIdx.y;                         // 0: label-only count, 1..A: annotator a-1
+    const int q = blockIdx.y;                         // < B: label-only count of image q; else annotator q - B
+    const int b = q < B ? q : (img_of ? img_of[q - B] : 0);
+    const uint8_t *lb = maps + (size_t)b * n;
+    const uint8_t *tb = maps + (size_t)q * n;         // annotator plane (q >= B)
     unsigned c0 = 0, c1 = 0, c2 = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const int y = p / W, x = p % W;
-        const bool bl = maps[p];
-        if (a == 0) {
+        const bool bl = lb[p];
+        if (q < B) {
             c0 += bl;
         } else {
-            const uint8_t *tb = maps + (size_t)a * n;
             const bool bt = tb[p];
-            c0 += bt && dilated5(maps, H, W, y, x);  // recall numerator
+            c0 += bt && dilated5(lb, H, W, y, x);    // recall numerator
             c1 += bt;                                  // recall denominator
             c2 += bl && dilated5(tb, H, W, y, x);    // precision numerator
         }
@@ -68,12 +75,12 @@ __global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, int A, 
         c2 += __shfl_xor(c2, m);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (a == 0) {
-            atomicAdd(&counts[0], (unsigned long long)c0);
+        if (q < B) {
+            atomicAdd(&counts[q], (unsigned long long)c0);
         } else {
-            atomicAdd(&counts[1 + 3 * (a - 1)], (unsigned long long)c0);
-            atomicAdd(&counts[2 + 3 * (a - 1)], (unsigned long long)c1);
-            atomicAdd(&counts[3 + 3 * (a - 1)], (unsigned long long)c2);
+            atomicAdd(&counts[B + 3 * (q - B)], (unsigned long long)c0);
+            atomicAdd(&counts[B + 3 * (q - B) + 1], (unsigned long long)c1);
+            atomicAdd(&counts[B + 3 * (q - B) + 2], (unsigned long long)c2);
         }
     }
 }
@@ -82,23 +89,42 @@ extern "C" size_t gcs_boundary_scratch_bytes(int A, int H, int W) {
     if (A <= 0 || H <= 0 || W <= 0) return 0;
     return (size_t)(A + 1) * H * W;
 }
+extern "C" size_t gcs_boundary_batch_scratch_bytes(int B, int T, int H, int W) {
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)(B + T) * H * W;
+}
+
+static int boundary_counts_launch(const int32_t *labels, const uint16_t *truth, const int32_t *img_of, int B, int T, int H,
+                                  int W, void *scratch, uint64_t *counts, hipStream_t stream, const char *who) {
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(B + 3 * T) * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return gcs_hip_fail(e, who);
+    uint8_t *maps = static_cast<uint8_t *>(scratch);
+    const int n = H * W;
+    const size_t total = (size_t)(B + T) * n;
+    hipLaunchKernelGGL(boundary_maps_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                       dim3(256), 0, stream, labels, truth, B, T, H, W, maps);
+    GCS_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(boundary_counts_kernel, dim3(min(B + T > 64 ? 32 : 256, (n + 255) / 256), B + T), dim3(256), 0, stream,
+                       maps, img_of, B, T, H, W, reinterpret_cast<unsigned long long *>(counts));
+    GCS_CHECK_LAUNCH(who);
+    return GCS_OK;
+}
 
 extern "C" int gcs_boundary_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, void *scratch,
                                    uint64_t *counts, gcs_stream_t stream) {
     if (!labels || !truth || !scratch || !counts) return gcs_fail(GCS_EINVAL, "gcs_boundary_counts: NULL pointer");
-    if (A <= 0 || A > 65535 || H <= 0 || W <= 0 || (long long)H * W * (A + 1) > 0x7fffffffLL)
+    if (A <= 0 || A > 65534 || H <= 0 || W <= 0 || (long long)H * W * (A + 1) > 0x7fffffffLL)
         return gcs_fail(GCS_EINVAL, "gcs_boundary_counts: bad shape");
-    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(1 + 3 * A) * sizeof(uint64_t), stream);
-    if (e != hipSuccess) return gcs_hip_fail(e, "gcs_boundary_counts(memset)");
-    uint8_t *maps = static_cast<uint8_t *>(scratch);
-    const int n = H * W;
-    hipLaunchKernelGGL(boundary_maps_kernel, dim3(min(2048, ((A + 1) * n + 255) / 256)), dim3(256), 0, stream, labels,
-                       truth, A, H, W, maps);
-    GCS_CHECK_LAUNCH("gcs_boundary_counts(maps)");
-    hipLaunchKernelGGL(boundary_counts_kernel, dim3(min(256, (n + 255) / 256), A + 1), dim3(256), 0, stream, maps, A, H,
-                       W, reinterpret_cast<unsigned long long *>(counts));
-    GCS_CHECK_LAUNCH("gcs_boundary_counts");
-    return GCS_OK;
+    return boundary_counts_launch(labels, truth, nullptr, 1, A, H, W, scratch, counts, stream, "gcs_boundary_counts");
+}
+
+extern "C" int gcs_boundary_counts_batch(const int32_t *labels, const uint16_t *truth, const int32_t *img_of, int B, int T,
+                                         int H, int W, void *scratch, uint64_t *counts, gcs_stream_t stream) {
+    if (!labels || !truth || !img_of || !scratch || !counts)
+        return gcs_fail(GCS_EINVAL, "gcs_boundary_counts_batch: NULL pointer");
+    if (B <= 0 || T <= 0 || B + T > 65535 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_boundary_counts_batch: bad shape");
+    return boundary_counts_launch(labels, truth, img_of, B, T, H, W, scratch, counts, stream, "gcs_boundary_counts_batch");
 }
 
 // ================================================================== connected regions (§8f-4)
@@ -213,20 +239,30 @@ extern "C" int gcs_connected_regions(const int32_t *labels, int B, int H, int W,
 // areas) and :160-181 (4-neighbour perimeter: image-border pixels, or pixels with a different 4-neighbour). One
 // thread per pixel; workgroup-private tables in LDS when they fit (k-means label maps: a few clusters, every
 // atomic on a handful of addresses), global atomics otherwise (connected regions: thousands of sparse rows).
+// Batched: blockIdx.y = image b with annotators first[b] .. first[b+1]-1 of the concatenated truth stack (first == NULL:
+// one image with annotators 0 .. A-1); hist [T][n_seg][stride], area / perim [B][n_seg].
 __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__restrict__ labels,
-                                                            const uint16_t *__restrict__ truth, int A, int H, int W,
+                                                            const uint16_t *__restrict__ truth,
+                                                            const int32_t *__restrict__ first, int A, int H, int W,
                                                             int n_seg, int stride, int use_lds,
                                                             unsigned *__restrict__ hist, unsigned *__restrict__ area,
                                                             unsigned *__restrict__ perim) {
-    extern __shared__ unsigned s_tab[];                        // [A][n_seg][stride] hist | [n_seg] area | [n_seg] perim
-    const int n_hist = A * n_seg * stride, n_tab = n_hist + 2 * n_seg;
+    extern __shared__ unsigned s_tab[];                        // [A_b][n_seg][stride] hist | [n_seg] area | [n_seg] perim
+    const int b = blockIdx.y;
+    const int t0 = first ? first[b] : 0, a_n = first ? first[b + 1] - first[b] : A;
+    const int P = H * W;
+    labels += (size_t)b * P;
+    truth += (size_t)t0 * P;
+    hist += (size_t)t0 * n_seg * stride;
+    area += (size_t)b * n_seg;
+    perim += (size_t)b * n_seg;
+    const int n_hist = a_n * n_seg * stride, n_tab = n_hist + 2 * n_seg;
     if (use_lds) {
         for (int i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = 0u;
         __syncthreads();
     }
     unsigned *t_hist = use_lds ? s_tab : hist, *t_area = use_lds ? s_tab + n_hist : area,
              *t_perim = use_lds ? s_tab + n_hist + n_seg : perim;
-    const int P = H * W;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const int l = labels[p];
         if ((unsigned)l >= (unsigned)n_seg) continue;          // caller passes n_seg = max + 1; never index outside
@@ -235,7 +271,7 @@ __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__res
         if (!edge) edge = labels[p - W] != l || labels[p + W] != l || labels[p - 1] != l || labels[p + 1] != l;
         atomicAdd(&t_area[l], 1u);
         if (edge) atomicAdd(&t_perim[l], 1u);
-        for (int a = 0; a < A; ++a) {
+        for (int a = 0; a < a_n; ++a) {
             const int t = truth[(size_t)a * P + p];
             if (t < stride) atomicAdd(&t_hist[((size_t)a * n_seg + l) * stride + t], 1u);
         }
@@ -249,6 +285,25 @@ __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__res
     }
 }
 
+static int region_counts_launch(const int32_t *labels, const uint16_t *truth, const int32_t *first, int B, int T, int Amax,
+                                int H, int W, int n_segments, int n_truth_labels, uint32_t *hist, uint32_t *area,
+                                uint32_t *perim, hipStream_t stream, const char *who) {
+    const size_t n_hist = (size_t)T * n_segments * n_truth_labels;
+    hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return gcs_hip_fail(e, who);
+    const size_t lds = ((size_t)Amax * n_segments * n_truth_labels + 2 * (size_t)n_segments) * sizeof(unsigned);
+    const int use_lds = lds <= 48 * 1024;
+    const int P = H * W;
+    int blocks = use_lds ? min(256, (P + 1023) / 1024) : min(2048, (P + 255) / 256);
+    if (B > 16) blocks = min(blocks, 32);
+    hipLaunchKernelGGL(region_counts_kernel, dim3(blocks, B), dim3(256), use_lds ? lds : 0, stream, labels, truth, first,
+                       Amax, H, W, n_segments, n_truth_labels, use_lds, hist, area, perim);
+    GCS_CHECK_LAUNCH(who);
+    return GCS_OK;
+}
+
 extern "C" int gcs_region_counts(const int32_t *labels, const uint16_t *truth, int A, int H, int W, int n_segments,
                                  int n_truth_labels, uint32_t *hist, uint32_t *area, uint32_t *perim,
                                  gcs_stream_t stream) {
@@ -256,18 +311,18 @@ extern "C" int gcs_region_counts(const int32_t *labels, const uint16_t *truth, i
     if (A <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL || n_segments <= 0 || n_truth_labels <= 0 ||
         (long long)A * n_segments * n_truth_labels > 0x3fffffffLL)
         return gcs_fail(GCS_EINVAL, "gcs_region_counts: bad shape");
-    const size_t n_hist = (size_t)A * n_segments * n_truth_labels;
-    hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)n_segments * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)n_segments * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return gcs_hip_fail(e, "gcs_region_counts(memset)");
-    const size_t lds = (n_hist + 2 * (size_t)n_segments) * sizeof(unsigned);
-    const int use_lds = lds <= 48 * 1024;
-    const int P = H * W;
-    const int blocks = use_lds ? min(256, (P + 1023) / 1024) : min(2048, (P + 255) / 256);
-    hipLaunchKernelGGL(region_counts_kernel, dim3(blocks), dim3(256), use_lds ? lds : 0, stream, labels, truth, A, H, W,
-                       n_segments, n_truth_labels, use_lds, hist, area, perim);
-    GCS_CHECK_LAUNCH("gcs_region_counts");
-    return GCS_OK;
+    return region_counts_launch(labels, truth, nullptr, 1, A, A, H, W, n_segments, n_truth_labels, hist, area, perim, stream,
+                                "gcs_region_counts");
 }
 
+extern "C" int gcs_region_counts_batch(const int32_t *labels, const uint16_t *truth, const int32_t *first, int B, int T,
+                                       int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist,
+                                       uint32_t *area, uint32_t *perim, gcs_stream_t stream) {
+    if (!labels || !truth || !first || !hist || !area || !perim)
+        return gcs_fail(GCS_EINVAL, "gcs_region_counts_batch: NULL pointer");
+    if (B <= 0 || B > 65535 || T <= 0 || max_annotators <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL ||
+        n_segments <= 0 || n_truth_labels <= 0 || (long long)T * n_segments * n_truth_labels > 0x3fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_region_counts_batch: bad shape");
+    return region_counts_launch(labels, truth, first, B, T, max_annotators, H, W, n_segments, n_truth_labels, hist, area,
+                                perim, stream, "gcs_region_counts_batch");
+}

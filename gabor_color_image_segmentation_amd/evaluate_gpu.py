@@ -134,3 +134,58 @@ def all_scores_device(labels, segments_truth) -> dict:
     out.update(region_scores_from_counts(hist, area, perim, n_truth, nx, ny))
     out["density"] = float(counts[0]) / float(nx * ny)           # metrics.py:157
     return out
+
+
+def all_scores_batch_device(labels, truth, first, img_of, n_truth, n_segments=None) -> list:
+    """Every number of ``evaluate.metrics.get_metrics()`` for a whole batch of device label maps in THREE launches
+    (boundary maps, boundary counts, region tables) and one device-to-host copy per table, instead of a scoring call
+    and two host round trips per image (metrics.py:58-201 loops over images in script.py:22).
+
+    labels: (B,H,W) int32 device tensor; truth / first / img_of / n_truth: ``PackedTruth.stack(ids)`` (or the same
+    layout built by hand): all annotator maps of image 0, then of image 1, ...; n_segments: max label + 1 over the
+    batch (default: read from the labels; metrics.py:51 per image is the image's own max + 1, applied below)."""
+    import torch
+    lib = _lib.load()
+    if labels.dtype != torch.int32 or labels.dim() != 3:
+        raise ValueError("labels must be a (B,H,W) int32 tensor")
+    b, h, w = labels.shape
+    truth = np.ascontiguousarray(truth, np.uint16)
+    t = truth.shape[0]
+    if truth.shape[1:] != (h, w) or len(first) != b + 1 or int(first[-1]) != t or len(img_of) != t:
+        raise ValueError("truth stack does not match the label batch")
+    if any(int(first[i + 1]) == int(first[i]) for i in range(b)):
+        raise ZeroDivisionError("an image has no annotator maps (metrics.py:74 divides by len(img_truth))")
+    dev = labels.device
+    labels = labels.contiguous()
+    seg_max = labels.reshape(b, -1).max(dim=1).values                   # per-image max label, one small copy below
+    truth_d = torch.from_numpy(truth.view(np.int16)).to(dev)
+    first_d = torch.from_numpy(np.ascontiguousarray(first, np.int32)).to(dev)
+    img_of_d = torch.from_numpy(np.ascontiguousarray(img_of, np.int32)).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    scratch = torch.empty(lib.gcs_boundary_batch_scratch_bytes(b, t, h, w), dtype=torch.uint8, device=dev)
+    counts = torch.empty(b + 3 * t, dtype=torch.int64, device=dev)
+    _lib.check(lib.gcs_boundary_counts_batch(labels.data_ptr(), truth_d.data_ptr(), img_of_d.data_ptr(), b, t, h, w,
+                                             scratch.data_ptr(), counts.data_ptr(), stream), "gcs_boundary_counts_batch")
+    seg_max = seg_max.cpu().numpy()
+    n_seg = int(n_segments) if n_segments is not None else int(seg_max.max()) + 1
+    stride = int(max(n_truth))
+    a_max = int(max(int(first[i + 1]) - int(first[i]) for i in range(b)))
+    hist = torch.empty((t, n_seg, stride), dtype=torch.int32, device=dev)
+    area = torch.empty((b, n_seg), dtype=torch.int32, device=dev)
+    perim = torch.empty((b, n_seg), dtype=torch.int32, device=dev)
+    _lib.check(lib.gcs_region_counts_batch(labels.data_ptr(), truth_d.data_ptr(), first_d.data_ptr(), b, t, a_max, h, w,
+                                           n_seg, stride, hist.data_ptr(), area.data_ptr(), perim.data_ptr(), stream),
+               "gcs_region_counts_batch")
+    counts = counts.cpu().numpy().astype(np.uint64)
+    hist, area, perim = hist.cpu().numpy(), area.cpu().numpy(), perim.cpu().numpy()
+    out = []
+    for i in range(b):
+        t0, t1 = int(first[i]), int(first[i + 1])
+        c = np.concatenate([counts[i:i + 1], counts[b + 3 * t0:b + 3 * t1]])   # the single-image layout [1 + 3A]
+        n_i = int(seg_max[i]) + 1                                                # metrics.py:51
+        res = {"regions": n_i}
+        res.update(scores_from_counts(c))
+        res.update(region_scores_from_counts(hist[t0:t1, :n_i], area[i, :n_i], perim[i, :n_i], n_truth[t0:t1], h, w))
+        res["density"] = float(c[0]) / float(h * w)
+        out.append(res)
+    return out

@@ -147,6 +147,14 @@ size_t gcs_boundary_scratch_bytes(int A, int H, int W);
 int gcs_boundary_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
                         void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
 
+/* Batched form: labels_dev int32 [B][H][W], truth_dev uint16 [T][H][W] = the annotator maps of image 0, then of image 1, ...
+ * (T = total annotators; ragged: BSD500 has 4-9 per image, groundtruth.py:33-50), img_of_dev int32 [T] = image of each
+ * annotator map. ONE pair of launches for the whole batch. counts_dev uint64 [B + 3T]: [b] = #boundary pixels of label map
+ * b; for annotator t: [B+3t], [B+3t+1], [B+3t+2] = the three sums above. scratch_dev: gcs_boundary_batch_scratch_bytes(). */
+size_t gcs_boundary_batch_scratch_bytes(int B, int T, int H, int W);
+int gcs_boundary_counts_batch(const int32_t *labels_dev, const uint16_t *truth_dev, const int32_t *img_of_dev, int B, int T,
+                              int H, int W, void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
+
 /* ---- region tables of one image ------------------------------------------ */
 
 /* Integer part of /root/reference/BSD_metrics/metrics.py:102-146 (undersegmentation: the label x annotator
@@ -158,6 +166,13 @@ int gcs_boundary_counts(const int32_t *labels_dev, const uint16_t *truth_dev, in
 int gcs_region_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int A, int H, int W,
                       int n_segments, int n_truth_labels, uint32_t *hist_dev, uint32_t *area_dev,
                       uint32_t *perim_dev, gcs_stream_t stream);
+
+/* Batched form (same ragged truth stack as gcs_boundary_counts_batch): first_dev int32 [B+1] = index of each image's first
+ * annotator map (first[B] = T), max_annotators = the largest per-image count. hist_dev uint32 [T][n_segments][n_truth_labels],
+ * area_dev / perim_dev uint32 [B][n_segments]. One launch for the whole batch. */
+int gcs_region_counts_batch(const int32_t *labels_dev, const uint16_t *truth_dev, const int32_t *first_dev, int B, int T,
+                            int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist_dev,
+                            uint32_t *area_dev, uint32_t *perim_dev, gcs_stream_t stream);
 
 /* ---- connected regions (SPEC.md §7) -------------------------------------- */
 

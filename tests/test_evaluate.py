@@ -101,3 +101,29 @@ def test_mat_loader_mirror_matches_the_fixture():
     assert len(segs) == int(INP["nseg_100080"])
     for a, s in enumerate(segs):
         assert np.array_equal(s, INP["seg_100080_%d" % a])
+
+
+def test_whole_dataset_truth_pack_matches_the_fixtures_and_the_mat_loader():
+    """tests/golden/bsd500_truth.npz (tools/pack_bsd_truth.py: the reference's own loader over all 500 ids) holds the same
+    maps as the per-image fixtures, and as the .mat mirror where the reference tree is present."""
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth, get_segment_from_filename
+    pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    assert len(pt) == 500 and int(pt.first[-1]) == 2696
+    assert sorted(pt.shape(i) for i in pt.ids)[0] == (321, 481) and sorted(pt.shape(i) for i in pt.ids)[-1] == (481, 321)
+    assert min(pt.n_annotators(i) for i in pt.ids) >= 4 and max(pt.n_annotators(i) for i in pt.ids) <= 9
+    for i in INP["ids"]:
+        i = str(i)
+        got = pt[i]
+        assert len(got) == int(INP["nseg_" + i])
+        for a, m in enumerate(got):
+            assert m.dtype == np.uint16 and np.array_equal(m, INP["seg_%s_%d" % (i, a)])
+    truth, first, img_of, n_truth = pt.stack(["100075", "100098"])
+    assert truth.shape[1:] == (321, 481) and first.tolist() == [0, pt.n_annotators("100075"), truth.shape[0]]
+    assert img_of.tolist() == [0] * first[1] + [1] * (truth.shape[0] - first[1]) and n_truth[0] == int(truth[0].max()) + 1
+    with pytest.raises(ValueError):
+        pt.stack(["100075", "100080"])                     # landscape + portrait
+    ref = "/root/reference/BSD_metrics/data/truth/"
+    if os.path.isdir(ref):
+        for i in ("2092", "97010", "100080"):
+            want = get_segment_from_filename(i, ref)
+            assert len(want) == len(pt[i]) and all(np.array_equal(x, y) for x, y in zip(want, pt[i]))

@@ -98,3 +98,74 @@ def test_gpu_region_tables_on_connected_regions(built):
         assert got[key] == ref[key], key
     for key in ("underseg", "undersegNP", "compactness"):
         assert abs(got[key] - ref[key]) <= 1e-12, key
+
+
+def _label_candidates(h, w, seed):
+    """Label maps that need no image: a 16x16 block grid, two halves and a seeded Voronoi partition (8 cells)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(0, 1, (8, 2)) * [h, w]
+    yy, xx = np.mgrid[:h, :w]
+    vor = np.argmin((yy[..., None] - pts[:, 0]) ** 2 + (xx[..., None] - pts[:, 1]) ** 2, axis=2).astype(np.int32)
+    return [((np.arange(h)[:, None] // 16) * ((w + 15) // 16) + np.arange(w)[None, :] // 16).astype(np.int32),
+            ((np.arange(w)[None, :] >= w // 2).astype(np.int32) * np.ones((h, 1), np.int32)), vor]
+
+
+def test_batched_gpu_scorer_equals_the_reference_numbers_on_the_golden_maps(built):
+    """The 12 golden maps (3 BSD ids x {oracle, halves, blocks, SLIC}) through gcs_boundary_counts_batch /
+    gcs_region_counts_batch (ragged annotator stack, one launch per table for the whole batch) give the reference's own
+    numbers (tests/golden/scoring_golden.json, produced by /root/reference/BSD_metrics/metrics.py)."""
+    import torch
+    from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_batch_device
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
+    inp = np.load(os.path.join(GOLD, "bsd_inputs.npz"))
+    path = np.load(os.path.join(GOLD, "path_golden.npz"))
+    maps = np.load(os.path.join(GOLD, "scoring_maps.npz"))
+    scores = json.load(open(os.path.join(GOLD, "scoring_golden.json")))
+    pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    for ids in (["100075", "100098"], ["100080"]):                       # one batch per image shape
+        for name in ("oracle", "halves", "blocks", "slic"):
+            labs = np.stack([_maps(i, inp, path, maps)[name] for i in ids])
+            got = all_scores_batch_device(torch.from_numpy(np.ascontiguousarray(labs)).cuda(), *pt.stack(ids))
+            for i, g in zip(ids, got):
+                ref = scores[i + "/" + name]
+                assert g["regions"] == ref["regions"], (i, name)
+                for key in ("recall", "precision", "underseg", "undersegNP", "density"):
+                    assert g[key] == ref[key], (i, name, key, g[key], ref[key])
+                assert abs(g["compactness"] - ref["compactness"]) <= 1e-15 * max(1.0, abs(ref["compactness"])), (i, name)
+
+
+def test_batched_gpu_scorer_on_sixty_further_ids_equals_the_host_mirror(built):
+    """Whole-dataset ingest: 60 more BSD ids straight from the packed ground truth (40 landscape,
+    20 portrait; 4-9 annotators each), three label maps per id, scored in batches of 20 images by the batched GPU scorer
+    and, one image at a time, by the host mirror of /root/reference/BSD_metrics/metrics.py (evaluate.metrics, itself pinned
+    to the reference's numbers) and by the single-image GPU scorer."""
+    import torch
+    from gabor_color_image_segmentation_amd.evaluate import metrics
+    from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_batch_device, all_scores_device
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
+    pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    land = [i for i in pt.ids if pt.shape(i) == (321, 481) and i not in ("100075", "100098")][::8][:40]
+    port = [i for i in pt.ids if pt.shape(i) == (481, 321) and i != "100080"][::7][:20]
+    assert len(land) == 40 and len(port) == 20
+    checked = 0
+    for group in (land[:20], land[20:], port):
+        h, w = pt.shape(group[0])
+        stack = pt.stack(group)
+        for v in range(3):
+            labs = np.stack([_label_candidates(h, w, seed=int(i))[v] for i in group])
+            dev = torch.from_numpy(labs).cuda()
+            got = all_scores_batch_device(dev, *stack)
+            for b, i in enumerate(group):
+                if (b + v) % 5 == 0:                                   # the host loops are slow: every 5th (id, map) pair
+                    m = metrics(np.zeros((h, w, 3), np.uint8), labs[b], pt[i])
+                    m.set_metrics()
+                    ref = m.get_metrics()
+                    assert got[b]["regions"] == ref["regions"]
+                    for key in ("recall", "precision", "fmeasure", "density"):
+                        assert got[b][key] == ref[key], (i, v, key)
+                    for key in ("underseg", "undersegNP", "compactness"):
+                        assert abs(got[b][key] - ref[key]) <= 1e-12, (i, v, key)
+                    checked += 1
+                if b % 7 == 0:
+                    assert got[b] == all_scores_device(dev[b], pt[i]), (i, v)
+    assert checked >= 36
