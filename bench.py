@@ -303,8 +303,7 @@ def main():
         if roofline["kernel"] == "gabor_mfma_kernel":
             big = max(e["grid_threads"] for e in cand)
             roofline["traffic"] = sum(e["hbm_bytes_corrected"] for e in cand if e["grid_threads"] == big) + \
-                sum(e["hbm_bytes_corrected"] for e in prof.get("gabor_pad_kernel", [])
-                    if e["grid_threads"] == max(x["grid_threads"] for x in prof["gabor_pad_kernel"]))
+                sum(e["hbm_bytes_corrected"] for e in prof.get("gabor_plane_kernel", []))
         else:
             roofline["traffic"] = max(cand, key=lambda e: e["grid_threads"])["hbm_bytes_corrected"]
         roofline["traffic_source"] = "profiles/hbm_traffic_latest.json (separate rocprofv3 --pmc run, batch %d)" % PER_GPU
@@ -354,7 +353,7 @@ def main():
                     ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="i8", data="synthetic",
                     config=dict(workload=f"batch {B}/GPU synthetic {W}x{H}x3 uint8 (seed 0), 4-scale x "
-                                         f"6-orientation Gabor bank ksize 15 on a 2-level octave pyramid, k={args.k}, "
+                                         f"6-orientation Gabor bank ksize {bank.ksize} on a {bank.n_levels}-level octave pyramid, k={args.k}, "
                                          f"n_iter={args.n_iter}",
                                 codebook=args.mode, global_batch=world * B, features="uint16 Q7, level L at 1/4^L resolution",
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"

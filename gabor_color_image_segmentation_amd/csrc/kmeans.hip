@@ -364,23 +364,31 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
             if (scls[i] == 0) {
                 *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
             } else {
-                // coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice
+                // coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice, each row into
+                // two fine rows = four 16-byte pieces of this lane's 64-byte region. Lanes are 64 bytes apart, so piece k
+                // of lanes l and l+2 would share banks (4-way conflicts: SQ_LDS_BANK_CONFLICT 0.4 M -> 17.7 M cycles per
+                // launch when every lane wrote its pieces in the same order). Lanes therefore start on different pieces:
+                // bit 2 of the lane picks which coarse row goes first, bit 1 which of its two pieces; the eight lanes of a
+                // ds_write_b128 group then cover 32 distinct banks.
+                const bool f = (lane >> 2) & 1;
+                const unsigned x0 = f ? (unsigned)v[2] : (unsigned)v[0], x1 = f ? (unsigned)v[3] : (unsigned)v[1];
+                const unsigned y0 = f ? (unsigned)v[0] : (unsigned)v[2], y1 = f ? (unsigned)v[1] : (unsigned)v[3];
                 v4i ra, rb;
-                ra[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x01000100u);
-                ra[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[0], 0x03020302u);
-                ra[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x01000100u);
-                ra[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[1], 0x03020302u);
-                rb[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[2], 0x01000100u);
-                rb[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[2], 0x03020302u);
-                rb[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[3], 0x01000100u);
-                rb[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)v[3], 0x03020302u);
-                if (scls[i] == 1) {
-                    lds_v4i_ptr d = reinterpret_cast<lds_v4i_ptr>(sdst[i]);
-                    d[0] = ra; d[1] = ra; d[2] = rb; d[3] = rb;
-                } else if (sl1[i]) {                      // a wave whose chunks straddle a level boundary
-                    lds_v4i_ptr d = reinterpret_cast<lds_v4i_ptr>(sdst[i]);
-                    d[0] = ra; d[1] = ra; d[2] = rb; d[3] = rb;
-                } else {
+                ra[0] = (int)__builtin_amdgcn_perm(0u, x0, 0x01000100u);
+                ra[1] = (int)__builtin_amdgcn_perm(0u, x0, 0x03020302u);
+                ra[2] = (int)__builtin_amdgcn_perm(0u, x1, 0x01000100u);
+                ra[3] = (int)__builtin_amdgcn_perm(0u, x1, 0x03020302u);
+                rb[0] = (int)__builtin_amdgcn_perm(0u, y0, 0x01000100u);
+                rb[1] = (int)__builtin_amdgcn_perm(0u, y0, 0x03020302u);
+                rb[2] = (int)__builtin_amdgcn_perm(0u, y1, 0x01000100u);
+                rb[3] = (int)__builtin_amdgcn_perm(0u, y1, 0x03020302u);
+                if (scls[i] == 1 || sl1[i]) {
+                    const int e16 = ((lane >> 1) & 1) * 16, f32 = f ? 32 : 0;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + e16) = ra;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + 16 - e16) = ra;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + e16) = rb;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + 16 - e16) = rb;
+                } else {                                  // a lane of a mixed wave whose chunk is not level 1
                     *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
                 }
             }

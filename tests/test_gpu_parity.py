@@ -142,13 +142,13 @@ def test_randomised_shapes_banks_and_codebooks(torch_cuda):
 
 def test_isqrt31_exhaustive(torch_cuda):
     """The 7-instruction exact integer square root of the Gabor epilogue (csrc/gabor.hip isqrt31) on EVERY n of its
-    domain, 0 ... 2 * 32642^2 (SPEC.md §3 bound on re^2 + im^2): one kernel, 2.1e9 values."""
+    domain and beyond: every n in [0, 2^31) (SPEC.md §3: re^2 + im^2 <= 2 * 32724^2 < 2^31): one kernel, 2.1e9 values."""
     import ctypes as C
     from gabor_color_image_segmentation_amd import _lib
     torch = torch_cuda
     lib = _lib.load()
     bad = torch.full((1,), 123, dtype=torch.int32, device="cuda")
-    n_max = 2 * 32642 ** 2
+    n_max = 2 ** 31 - 1
     _lib.check(lib.gcs_selftest_isqrt(n_max, bad.data_ptr(), torch.cuda.current_stream().cuda_stream), "selftest")
     assert int(bad.item()) == 0
 

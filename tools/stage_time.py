@@ -2,7 +2,7 @@
 """Time the stages of the path for any bank: tools/stage_time.py [B] [n_scales] [n_orient] [k] [mode] [H] [W].
 
 Prints the Gabor stage, one Lloyd pass and the whole segment_device step (n_iter = 10) on B synthetic
-321x481 images, with the algorithmic GB/s of the pass ((2D+1) B/px) and the int8 TOP/s of the bank.
+321x481 images, with the algorithmic GB/s of the pass (pyramid-resident bytes) and the int8 TOP/s of the bank.
 BASELINE config 4 (8x8 bank, D = 192): tools/stage_time.py 64 8 8."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,6 +39,11 @@ seg.ops.kmeans_init(ws["feats"], B, H, W, k, n_sets, ws["cent"])
 tp = timed(lambda: seg.ops.assign_accumulate(ws["feats"], ws["cent"], B, H, W, k, n_sets, ws["labels"], ws["partials"]))
 ts = timed(lambda: seg.segment_device(imgs, mode=mode), n=5, warm=1)
 px = B * H * W
-print(f"B={B} {W}x{H} bank {ns}x{no} D={D} k={k} {mode}: gabor {tg:.3f} ms ({2*225*4*seg.bank.n_filters*3*px/tg/1e9:.0f} TOP/s, "
-      f"{(3+2*D)*px/tg/1e6:.0f} GB/s) | pass {tp:.3f} ms ({(2*D+1)*px/tp/1e6:.0f} GB/s alg) | "
-      f"step {ts:.2f} ms = {px/ts/1e3:.0f} Mpix/s")
+bank = seg.bank
+lv = [(3 * min(2, ns - 2 * L) * no, 4 ** L) for L in range(bank.n_levels)]     # (planes, pixel divisor) per pyramid level
+feat_b = 2 * sum(d / q for d, q in lv)                                         # feature bytes per full-resolution pixel
+ops = sum(2 * bank.ksize ** 2 * (4 * d // 3) * 3 * px / q for d, q in lv)      # int8 MACs x 2
+print(f"B={B} {W}x{H} bank {ns}x{no} D={D} ({bank.n_levels} pyramid levels, {feat_b:.0f} feature B/px) k={k} {mode}: "
+      f"gabor {tg:.3f} ms ({ops/tg/1e9:.0f} TOP/s int8 two-digit MFMA, exact int32 accumulation"
+      f"{' - BASELINE.json names bf16 for the 64-filter bank' if ns * no == 64 else ''}; {(3+feat_b)*px/tg/1e6:.0f} GB/s) | "
+      f"pass {tp:.3f} ms ({(feat_b+1)*px/tp/1e6:.0f} GB/s alg) | step {ts:.2f} ms = {px/ts/1e3:.0f} Mpix/s")
