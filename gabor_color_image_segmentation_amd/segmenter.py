@@ -30,6 +30,19 @@ def _torch():
     return torch
 
 
+def _on_device(fn):
+    """Run a HipOps entry point with the plan's device current (a Segmenter on cuda:1 used while cuda:0 is current
+    would otherwise launch on the wrong device) after checking where its tensor arguments live."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        self._check_dev(*[a for a in list(args) + list(kw.values()) if hasattr(a, "data_ptr") and hasattr(a, "device")])
+        with self.torch.cuda.device(self.device):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class HipOps:
     """Thin pointer-passer over the C ABI for one device. Stateless apart from the bank."""
 
@@ -40,6 +53,8 @@ class HipOps:
         self.lib = _lib.load()
         self.torch = torch
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.bank = bank
         ns, no = bank.n_scales, bank.n_orient
         self._bk = (ns, no)                      # the bank as the C ABI describes it
@@ -68,7 +83,15 @@ class HipOps:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
+    def _check_dev(self, *tensors):
+        """Launches go through ctypes on the calling thread's CURRENT device: every tensor must live on this plan's
+        device, and the calls below run inside ``torch.cuda.device(self.device)`` (see ``_on_device``)."""
+        for t in tensors:
+            if t.device != self.device:
+                raise ValueError(f"tensor on {t.device}, this Segmenter's kernels run on {self.device}")
+
     # ---- device entry points
+    @_on_device
     def gabor_features(self, imgs, feats):
         b, h, w, _ = imgs.shape
         need = self.lib.gcs_gabor_workspace_bytes(b, h, w, self.bank.n_scales)
@@ -80,6 +103,7 @@ class HipOps:
                                                feats.data_ptr(), self._stream()),
                    "gcs_gabor_features")
 
+    @_on_device
     def features_unpack(self, feats, b, h, w):
         d = self.bank.n_features
         out = self.torch.empty((b, d, h, w), dtype=self.torch.int16, device=self.device)
@@ -87,10 +111,12 @@ class HipOps:
                                                 self._stream()), "gcs_features_unpack")
         return out
 
+    @_on_device
     def kmeans_init(self, feats, b, h, w, k, n_sets, cent):
         _lib.check(self.lib.gcs_kmeans_init(feats.data_ptr(), b, h, w, *self._bk, k, n_sets,
                                             cent.data_ptr(), self._stream()), "gcs_kmeans_init")
 
+    @_on_device
     def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None, reverse=False):
         lo, hi = rows if rows is not None else (0, h)
         _lib.check(self.lib.gcs_kmeans_assign_accumulate(
@@ -98,6 +124,7 @@ class HipOps:
             1 if reverse else 0, labels.data_ptr(), partials.data_ptr(), self._stream()),
             "gcs_kmeans_assign_accumulate")
 
+    @_on_device
     def features_gather(self, feats, b, h, w, byx):
         """byx: (n,3) int32 device tensor of (image, row, col); image < 0 -> zero row. -> (n,D) int16."""
         n = byx.shape[0]
@@ -107,20 +134,24 @@ class HipOps:
                    "gcs_features_gather")
         return out
 
+    @_on_device
     def reduce(self, partials, b, h, w, k, n_sets, sums):
         _lib.check(self.lib.gcs_kmeans_reduce(partials.data_ptr(), b, h, w, self.bank.n_features, k,
                                               n_sets, sums.data_ptr(), self._stream()), "gcs_kmeans_reduce")
 
+    @_on_device
     def finalize(self, sums, n_sets, k, cent):
         _lib.check(self.lib.gcs_kmeans_finalize(sums.data_ptr(), n_sets, k, self.bank.n_features,
                                                 cent.data_ptr(), self._stream()), "gcs_kmeans_finalize")
 
+    @_on_device
     def reduce_finalize(self, partials, b, h, w, k, n_sets, sums, cent):
         """Single-rank update in one launch (reduce + finalize; no collective in between)."""
         _lib.check(self.lib.gcs_kmeans_reduce_finalize(partials.data_ptr(), b, h, w, self.bank.n_features, k, n_sets,
                                                        sums.data_ptr(), cent.data_ptr(), self._stream()),
                    "gcs_kmeans_reduce_finalize")
 
+    @_on_device
     def connected_regions(self, labels_i32, out):
         """SPEC.md §7 on an int32 (B,H,W) device tensor."""
         b, h, w = labels_i32.shape
@@ -128,10 +159,12 @@ class HipOps:
         _lib.check(self.lib.gcs_connected_regions(labels_i32.data_ptr(), b, h, w, scratch.data_ptr(),
                                                   out.data_ptr(), self._stream()), "gcs_connected_regions")
 
+    @_on_device
     def labels_widen(self, labels, b, h, w, out):
         _lib.check(self.lib.gcs_labels_widen(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
                    "gcs_labels_widen")
 
+    @_on_device
     def labels_raster_u8(self, labels, b, h, w, out):
         _lib.check(self.lib.gcs_labels_raster_u8(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
                    "gcs_labels_raster_u8")

@@ -105,17 +105,22 @@ def _big_strip_worker(rank, world, port, height, width, tmp):
 
 @pytest.mark.gpu
 def test_config5_size_2048_sharded_equals_unsharded_on_gpu(tmp_path, built):
-    """BASELINE config 5's real tile size: one 2048x2048 image, 2 row strips with halo == the unsharded GPU result
-    (the unsharded path itself is pinned to the oracle at smaller sizes)."""
+    """BASELINE config 5's real tile size: one 2048x2048 image, 2 row strips with halo == the unsharded GPU result == the
+    C oracle's label map of the whole image."""
     from gabor_color_image_segmentation_amd import Segmenter
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     height = width = 2048
     port = 35500 + (os.getpid() % 2000)
     mp.spawn(_big_strip_worker, args=(2, port, height, width, str(tmp_path)), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / f"big_{r}.npy") for r in range(2)], axis=1)
-    ref = Segmenter(n_iter=4).segment_batch(synthetic_batch(1, height, width, seed=41), mode="global")
+    imgs = synthetic_batch(1, height, width, seed=41)
+    ref = Segmenter(n_iter=4).segment_batch(imgs, mode="global")
     assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.uint8))
     assert len(np.unique(ref)) > 1
+    # and both equal the C oracle at this size (4.2 Mpix: a few seconds with OpenMP)
+    from oracle import c_oracle as co, spec_oracle as so
+    tapq, shift = so.bank()
+    assert np.array_equal(ref, co.segment_batch(imgs, tapq, shift, 6, n_iter=4, mode="global"))
 
 
 def _rccl_worker(rank, port, tmp):

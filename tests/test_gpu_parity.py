@@ -168,3 +168,32 @@ def test_pyramid_levels_with_odd_sizes_and_deep_banks(torch_cuda):
             ref = so.gabor_features(imgs[b], tapq, shift, no)
             bad = np.argwhere(got[b] != ref)
             assert bad.size == 0, ((h, w), (ns, no), len(bad), bad[:4])
+
+
+def test_host_path_variants_agree_with_the_device_path(torch_cuda):
+    """segment_batch (host array in, host array out: pinned staging, chunked upload on a second stream, labels copied
+    into a fresh pinned buffer) against segment_device, for batch sizes around the chunk count, both codebook modes and
+    both output dtypes; results are fresh arrays the caller owns (a later call does not change an earlier result)."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    torch = torch_cuda
+    seg = Segmenter(n_iter=3)
+    keep = []
+    for b in (1, 2, 3, 5, 9):
+        imgs = _synth(b, 40 + b, 72, seed=50 + b)
+        for mode in ("per_image", "global"):
+            want = seg.segment_device(torch.from_numpy(imgs).cuda(), mode=mode).cpu().numpy()
+            got32 = seg.segment_batch(imgs, mode=mode)
+            got8 = seg.segment_batch(imgs, mode=mode, out_dtype=np.uint8)
+            assert got32.dtype == np.int32 and got8.dtype == np.uint8 and got32.shape == want.shape
+            assert np.array_equal(got32, want) and np.array_equal(got8, want)
+            keep.append((got32, want))
+    for got, want in keep:                                  # earlier results were not overwritten by later calls
+        assert np.array_equal(got, want)
+    assert np.array_equal(seg(imgs[0]), want[0] if mode == "per_image" else seg.segment_device(
+        torch.from_numpy(imgs[:1]).cuda()).cpu().numpy()[0])
+    with pytest.raises(ValueError):
+        seg.segment_batch(imgs, out_dtype=np.int64)
+    with pytest.raises(ValueError):
+        Segmenter(connectivity=True).segment_batch(imgs, out_dtype=np.uint8)
+    with pytest.raises(ValueError):
+        seg.segment_device(torch.from_numpy(imgs))          # host tensor handed to the device API
