@@ -359,6 +359,7 @@ def main():
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"
                                 if args.mode == "global" else f"dp{world} (independent images)"),
                     roofline=roofline, cpu_baseline=cpu, kernels=kernels,
+                    slab_placement_ms=[round(x, 4) for x in getattr(seg, "slab_placement_ms", [])],
                     # whole job against the HBM roof: Gabor + n_iter passes, pyramid-resident bytes per pixel (and the
                     # un-fused uint16 definition of SURVEY.md §8d beside it), per GPU
                     end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * (feat_b + 1), 1),

@@ -269,8 +269,42 @@ class Segmenter:
             ws = dict(feats=self.ops.feature_slab(g, h, w), labels=self.ops.label_slab(g, h, w),
                       partials=self.ops.partial_slab(g, h, w, self.k),
                       cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
+            self._place_slab(ws, g, h, w, n_sets)
             self._ws = {key: ws}          # keep one shape resident
         return ws
+
+    def _place_slab(self, ws, g, h, w, n_sets):
+        """Pick the feature-slab allocation the Lloyd pass streams fastest (large slabs only).
+
+        Measured on MI355X (tools/slab_placement.py, profiles/r2_notes.md): the SAME pass kernel on the SAME bytes runs
+        6-7 % faster or slower depending on which 0.9 GB allocation holds them (0.169 vs 0.180 ms, stable per allocation
+        for the life of the process). So a few candidate allocations are timed once, with the pass kernel itself on
+        whatever bytes they hold, and the fastest is kept; the others go back to the allocator. GCS_SLAB_CANDIDATES=1
+        switches this off."""
+        n_cand = int(os.environ.get("GCS_SLAB_CANDIDATES", "6"))
+        n_cand = min(n_cand, (24 << 30) // max(1, ws["feats"].numel()))      # at most 24 GB of candidates
+        if n_cand <= 1 or not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20):
+            return
+        torch = _torch()
+        cands = [ws["feats"]] + [self.ops.feature_slab(g, h, w) for _ in range(n_cand - 1)]
+        best = [float("inf")] * len(cands)
+        with torch.cuda.device(self.ops.device):
+            for s in cands:
+                s.zero_()                                  # defined bytes: the timing must not depend on stale data
+            for rnd in range(3):
+                for i, s in enumerate(cands):
+                    for rev in (False, True):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        self.ops.assign_accumulate(s, ws["cent"], g, h, w, self.k, n_sets, ws["labels"], ws["partials"],
+                                                   reverse=rev)
+                        e1.record()
+                        e1.synchronize()
+                        if rnd and rev:
+                            best[i] = min(best[i], e0.elapsed_time(e1))
+        keep = min(range(len(cands)), key=lambda i: best[i])
+        ws["feats"] = cands[keep]
+        self.slab_placement_ms = best                      # diagnostics (bench.py prints it)
 
     def group_size(self, b, h, w, mode):
         if mode == "global":
