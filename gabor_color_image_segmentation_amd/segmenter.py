@@ -243,6 +243,11 @@ def shard_rows(height: int, world: int, rank: int, n_levels: int = 2):
     return r0, r1, max(0, r0 - halo), min(height, r1 + halo)
 
 
+def s1_of(bounds, r):
+    """End row (exclusive) of rank r's strip, halo included: what its lower neighbour has to send it."""
+    return bounds[r][3]
+
+
 class Segmenter:
     """Reusable plan: bank on device + cached workspaces. ``__call__`` is the slot."""
 
@@ -281,9 +286,11 @@ class Segmenter:
         for the life of the process). So a few candidate allocations are timed once, with the pass kernel itself on
         whatever bytes they hold, and the fastest is kept; the others go back to the allocator. GCS_SLAB_CANDIDATES=1
         switches this off."""
+        if not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20):
+            return
         n_cand = int(os.environ.get("GCS_SLAB_CANDIDATES", "6"))
         n_cand = min(n_cand, (24 << 30) // max(1, ws["feats"].numel()))      # at most 24 GB of candidates
-        if n_cand <= 1 or not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20):
+        if n_cand <= 1:
             return
         torch = _torch()
         cands = [ws["feats"]] + [self.ops.feature_slab(g, h, w) for _ in range(n_cand - 1)]
@@ -408,6 +415,53 @@ class Segmenter:
             out.copy_(res)
             return out
         return res.contiguous()
+
+    def segment_owned_rows_device(self, owned, height, dist_group=None):
+        """Row-sharded images where every rank holds ONLY its own rows on its device (BASELINE config 5, option (ii) of
+        SURVEY §8e): the halo rows the Gabor stage needs are fetched from the neighbouring ranks device to device
+        (``torch.distributed`` point-to-point: RCCL send / recv over xGMI on a multi-GPU node; gloo in the tests), then
+        the strip runs through ``segment_rows_sharded_device``.
+
+        ``owned``: (B, r1-r0, W, 3) uint8 device tensor = rows [r0, r1) of B images of ``height`` rows, with
+        (r0, r1) = ``shard_rows(height, world, rank, n_levels)[:2]``. Every rank must own at least the halo
+        (``7 * 2**(n_levels-1)`` rows), so that a halo comes from ONE neighbour. Returns the (B, r1-r0, W) int32 labels."""
+        torch = _torch()
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized()):
+            raise RuntimeError("segment_owned_rows_device needs torch.distributed (one rank per row strip)")
+        world, rank = td.get_world_size(dist_group), td.get_rank(dist_group)
+        nl = self.bank.n_levels
+        r0, r1, s0, s1 = shard_rows(height, world, rank, nl)
+        owned = owned.contiguous()
+        b, ho, w, _ = owned.shape
+        if ho != r1 - r0:
+            raise ValueError(f"rank {rank} owns rows [{r0}, {r1}) of {height}: got {ho} rows")
+        halo = 7 << (nl - 1)
+        bounds = [shard_rows(height, world, r, nl) for r in range(world)]
+        if world > 1 and min(x[1] - x[0] for x in bounds) < halo:
+            raise ValueError(f"every rank must own at least {halo} rows for a single-hop halo exchange")
+        up, down = rank - 1, rank + 1
+        gloo_host = owned.is_cuda and td.get_backend(dist_group) == "gloo"      # gloo moves host memory only
+
+        def wire(t):
+            return t.cpu() if gloo_host else t
+        ops, recv_top, recv_bot = [], None, None
+        peer = (lambda r: td.get_global_rank(dist_group, r)) if dist_group is not None else (lambda r: r)
+        if up >= 0:                                          # my first rows are the upper neighbour's bottom halo
+            ops.append(td.P2POp(td.isend, wire(owned[:, :s1_of(bounds, up) - r0].contiguous()), peer(up), dist_group))
+            recv_top = torch.empty((b, r0 - s0, w, 3), dtype=torch.uint8, device="cpu" if gloo_host else owned.device)
+            ops.append(td.P2POp(td.irecv, recv_top, peer(up), dist_group))
+        if down < world:                                     # my last rows are the lower neighbour's top halo
+            ops.append(td.P2POp(td.isend, wire(owned[:, bounds[down][2] - r0:].contiguous()), peer(down), dist_group))
+            recv_bot = torch.empty((b, s1 - r1, w, 3), dtype=torch.uint8, device="cpu" if gloo_host else owned.device)
+            ops.append(td.P2POp(td.irecv, recv_bot, peer(down), dist_group))
+        if ops:
+            for req in td.batch_isend_irecv(ops):
+                req.wait()
+        parts = ([recv_top.to(owned.device)] if recv_top is not None else []) + [owned] + \
+                ([recv_bot.to(owned.device)] if recv_bot is not None else [])
+        strip = torch.cat(parts, dim=1) if len(parts) > 1 else owned
+        return self.segment_rows_sharded_device(strip, r0, r1, s0, height, dist_group)
 
     def features_device(self, imgs):
         """Canonical (B,D,H,W) uint16 features as an int16 tensor (tests / debugging)."""

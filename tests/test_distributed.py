@@ -218,3 +218,55 @@ def test_bench_two_ranks_as_the_driver_launches_it(tmp_path, built):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and np.isfinite(d["value"]) and d["steps"] == 2
     assert d["config"]["codebook"] == "global" and "all-reduce" in d["config"]["parallelism"]
+
+
+def _owned_rows_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gabor_color_image_segmentation_amd import Segmenter, make_bank, shard_rows
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(b, height, width, seed=13)
+    r0, r1, _, _ = shard_rows(height, world, rank)
+    owned = torch.from_numpy(np.ascontiguousarray(imgs[:, r0:r1]))             # this rank never sees a neighbour's rows
+    if use_gpu:
+        seg = Segmenter(k=k, n_iter=n_iter, device="cuda:0")
+        owned = owned.cuda()
+    else:
+        from fake_ops import OracleOps
+        seg = Segmenter(k=k, n_iter=n_iter, ops=OracleOps(make_bank()))
+    out = seg.segment_owned_rows_device(owned, height)
+    np.save(os.path.join(tmp, f"owned_{rank}.npy"), out.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_between_ranks_equals_unsharded_oracle(tmp_path, world):
+    """BASELINE config 5 with the cross-rank halo exchange (SURVEY §8e option (ii)): every rank holds only its own rows;
+    the 14 halo rows per interior edge travel rank to rank (point-to-point), nothing comes from a host copy of the whole
+    image. Result == the unsharded oracle."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    from oracle import spec_oracle as so
+    port = 38500 + (os.getpid() % 2000) + world
+    b, height, width = 2, 72, 40
+    mp.spawn(_owned_rows_worker, args=(world, port, b, height, width, 3, 5, str(tmp_path), False), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)], axis=1)
+    ref = so.segment_batch(synthetic_batch(b, height, width, seed=13), mode="global", k=5, n_iter=3)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_halo_exchange_on_gpu_three_ranks(tmp_path, built):
+    """Same through the HIP kernels: three processes share cuda:0, halos are exchanged between their device tensors (gloo
+    carries them here, RCCL send / recv on a multi-GPU node), against the C oracle."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    from oracle import c_oracle as co, spec_oracle as so
+    port = 39500 + (os.getpid() % 2000)
+    b, height, width = 1, 200, 136
+    mp.spawn(_owned_rows_worker, args=(3, port, b, height, width, 5, 8, str(tmp_path), True), nprocs=3, join=True)
+    got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(3)], axis=1)
+    tapq, shift = so.bank()
+    ref = co.segment_batch(synthetic_batch(b, height, width, seed=13), tapq, shift, 6, k=8, n_iter=5, mode="global")
+    assert np.array_equal(got, ref)
