@@ -237,12 +237,18 @@ constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 2
 // DSTEPS = assign K-steps (16 planes = 32 byte-features each); LDS holds ROWS = 16*DSTEPS plane rows (>= D + 1:
 // the spare row D is the count row); the update has NT = 2*DSTEPS N-tiles (8 planes = 16 byte-planes each).
 // NST = 16-byte staging chunks per thread >= ceil(tile_bytes / 4096); surplus chunks re-copy the tile's last chunk.
-template <int KT, int NST, int DSTEPS>
-__global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
-                                     : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
+// WAVES = 4 (narrow pass: wave w owns block w of the tile) or 8 (wide pass: 131 KB of LDS allow one workgroup per CU, so
+// it brings 8 waves: wave w works on block w & 3; in the assign phase it takes the block's 32-pixel half w >> 2, in the
+// update phase all 64 pixels for half of the plane tiles -> half the accumulators, twice the waves to hide latency).
+template <int KT, int NST, int DSTEPS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
+                                          : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
+                                          : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
+    constexpr int NTHR = 64 * WAVES;                         // threads per workgroup
+    constexpr int NT_OWN = WAVES == 8 ? (KP_NT + 1) / 2 : KP_NT;   // update plane tiles a wave accumulates
     // compact copy of pyramid levels >= 2 of one tile (level 1 is replicated straight from the staging registers):
     // at most (D / 2) * 32 bytes plus 16-byte padding per level; sized for the worst case of the bucket
     constexpr int KP_COARSE = DSTEPS == KP_DSTEPS_NARROW ? 40 * 32 + 64 : 104 * 32 + 64;
@@ -251,7 +257,10 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = tid >> 6;                                // 0 .. WAVES-1
+    const int wave = wid & 3;                                // the block of the tile this wave works on
+    const int half = wid >> 2;                               // WAVES == 8: which half of the assign / update work
     const int b = blockIdx.y, part = blockIdx.x;
     const int D = lo.D;
     const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16 in PHYSICAL
     //      plane order, stored offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D.
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
-    for (int i = tid; i < 8 * KT * KP_ROWS; i += KP_TP) {
+    for (int i = tid; i < 8 * KT * KP_ROWS; i += NTHR) {
         const int j = i / KP_ROWS, r = i % KP_ROWS;
         cs[i] = (j < K && r < D) ? (uint16_t)(cset[j * D + gcs_logical_of_plane(lo, r)] ^ 0x8080u) : (uint16_t)0;
     }
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     //      key_j = base_j - 32 R0 - 8192 R1 - 2^21 R2 = 16 * score_j + j, so ONE 64-bit minimum yields the
     //      best score and the lowest index on ties. 16 lanes per cluster, folded with lane shuffles.
     {
-      for (int j = tid >> 4; j < 16; j += KP_TP / 16) {
+      for (int j = tid >> 4; j < 16; j += NTHR / 16) {
         const int sub = tid & 15;
         long long nrm = 0, scl = 0, sch = 0;
         if (j < K)
@@ -317,9 +326,9 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     __syncthreads();                                   // scratch reads done: the tile buffer is free again
     // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
     if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
-    v4i accu[KP_NT];
+    v4i accu[NT_OWN];
 #pragma unroll
-    for (int nt = 0; nt < KP_NT; ++nt) accu[nt] = v4i{0, 0, 0, 0};
+    for (int nt = 0; nt < NT_OWN; ++nt) accu[nt] = v4i{0, 0, 0, 0};
 
     // ---- staging: the tile is ONE contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
     //      ci = tid + 256*i is 16 bytes at byte 16*ci:
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     bool sl1[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-        const int ci = min(tid + KP_TP * i, nchunk - 1);
+        const int ci = min(tid + NTHR * i, nchunk - 1);
         ssrc[i] = ci;
         const int c1 = ci - n0;
         const bool l1 = c1 >= 0 && c1 < n1;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
             const int side = 8 >> L;                              // level-L pixels per block side
             const unsigned char *srcL = s_coarse + (lo.off[L] - lo.off[2]);
             const int items = lo.DL[L] * 32;                      // (plane, block in tile, fine row)
-            for (int it = tid; it < items; it += KP_TP) {
+            for (int it = tid; it < items; it += NTHR) {
                 const int rr = it >> 5, grp = it & 31;
                 const int blkq = grp >> 3, iy = grp & 7;
                 const unsigned char *s = srcL + (((rr * 4 + blkq) * side + (iy >> L)) * side) * 2;
@@ -457,7 +466,8 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
         const int blk = 4 * tile + wave;
         // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub_i = 0; sub_i < (WAVES == 8 ? 1 : 2); ++sub_i) {
+            const int sub = WAVES == 8 ? half : sub_i;
             const int n = lane & 31, h = lane >> 5;
             const int pl = wave * 64 + sub * 32 + n;
             v16i acc[KT];
@@ -523,7 +533,8 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
                 labels[((size_t)b * ntiles + tile) * KP_TP + pl] = (uint8_t)bj;
             }
         }
-        // -------- update: one-hot MFMA over this wave's 64 pixels
+        if (WAVES == 8) __syncthreads();                       // the block's labels come from two waves
+        // -------- update: one-hot MFMA over the block's 64 pixels
         {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
             v4i oh;
@@ -534,7 +545,8 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
                 oh[i] = (int)(~y & 0x80808080u);                            // digit -128 where label == un
             }
 #pragma unroll
-            for (int nt = 0; nt < KP_NT; ++nt) {
+            for (int nti = 0; nti < NT_OWN; ++nti) {
+                const int nt = WAVES == 8 ? min(half * NT_OWN + nti, KP_NT - 1) : nti;    // (a clamped duplicate is dropped below)
                 const int d = 8 * nt + (un >> 1);
                 const v4i *src = reinterpret_cast<const v4i *>(&s_tile[d * KP_PITCH + (wave * 64 + 16 * ug) * 2]);
                 const v4i w0 = src[0], w1 = src[1];
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
                 bx_[1] = (int)__builtin_amdgcn_perm((unsigned)w0[3], (unsigned)w0[2], usel);
                 bx_[2] = (int)__builtin_amdgcn_perm((unsigned)w1[1], (unsigned)w1[0], usel);
                 bx_[3] = (int)__builtin_amdgcn_perm((unsigned)w1[3], (unsigned)w1[2], usel);
-                accu[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[nt], 0, 0, 0);
+                accu[nti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[nti], 0, 0, 0);
             }
         }
         if (reverse) {                                           // next block of this wave: 4 * parts blocks back / on
@@ -561,21 +573,24 @@ __global__ __launch_bounds__(KP_TP, (DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NS
     // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row: every wave
     //      parks its registers in its own slice of the tile buffer (no zero-fill, no atomics), one barrier.
     constexpr int RW = KP_NT * 16;                            // byte-planes per cluster row
-    int *red = reinterpret_cast<int *>(s_tile);               // [KP_TP / 64 waves][16][RW]
-    static_assert((KP_TP / 64) * 16 * RW * 4 <= KP_ROWS * KP_PITCH, "fold buffer exceeds the tile buffer");
+    int *red = reinterpret_cast<int *>(s_tile);               // [4 blocks of the tile][16][RW]
+    static_assert(4 * 16 * RW * 4 <= KP_ROWS * KP_PITCH, "fold buffer exceeds the tile buffer");
 #pragma unroll
-    for (int nt = 0; nt < KP_NT; ++nt)
+    for (int nti = 0; nti < NT_OWN; ++nti) {
+        const int nt = WAVES == 8 ? half * NT_OWN + nti : nti;
+        if (nt < KP_NT)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[nt][e];
+            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[nti][e];
+    }
     __syncthreads();
     const int D1 = D + 1;
     auto folded = [&](int j, int bp) {
         int s = 0;
 #pragma unroll
-        for (int w = 0; w < KP_TP / 64; ++w) s += red[(w * 16 + j) * RW + bp];
+        for (int w = 0; w < 4; ++w) s += red[(w * 16 + j) * RW + bp];
         return -(long long)s / 128;                           // the one-hot digit is -128
     };
-    for (int i = tid; i < K * D1; i += KP_TP) {
+    for (int i = tid; i < K * D1; i += NTHR) {
         const int j = i / D1, e = i % D1;                     // e = LOGICAL feature (or D = the count)
         const long long nj = folded(j, cnt_bp);
         long long out = nj;
@@ -628,11 +643,13 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     const int D = lo.D;
     if (D < 16 * KP_DSTEPS_WIDE) { // matrix-core pass (every BASELINE bank: 4x6 -> D = 72, 8x8 -> D = 192)
         const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
-#define GCS_KP_LAUNCH(KT_, NST_, DS_)                                                                             \
-    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_>), dim3(parts, B), dim3(KP_TP), 0, stream,         \
-                       reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,   \
+#define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
+                       reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
                        reverse ? 1 : 0, row_lo, row_hi, labels, partials)
-        const int nst = (lo.tile_bytes / 16 + KP_TP - 1) / KP_TP;     // staging chunks per thread
+#define GCS_KP_LAUNCH(KT_, NST_, DS_) GCS_KP_LAUNCHW(KT_, NST_, DS_, 4)
+        const int nchunk = lo.tile_bytes / 16;
+        const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
         if (D < 16 * KP_DSTEPS_NARROW) {
             if (k <= 8) {
                 if (nst <= 3) { GCS_KP_LAUNCH(1, 3, KP_DSTEPS_NARROW); }
@@ -644,7 +661,8 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
                 else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
             }
         } else if (k <= 8) {
-            if (nst <= 10) { GCS_KP_LAUNCH(1, 10, KP_DSTEPS_WIDE); }
+            // pyramid banks (config 4: 2 040 chunks per tile) fit 5 chunks per thread of an 8-wave workgroup without spills
+            if ((nchunk + 511) / 512 <= 5) { GCS_KP_LAUNCHW(1, 5, KP_DSTEPS_WIDE, 8); }
             else if (nst <= 18) { GCS_KP_LAUNCH(1, 18, KP_DSTEPS_WIDE); }
             else { GCS_KP_LAUNCH(1, 26, KP_DSTEPS_WIDE); }
         } else {
@@ -652,6 +670,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
             else if (nst <= 18) { GCS_KP_LAUNCH(2, 18, KP_DSTEPS_WIDE); }
             else { GCS_KP_LAUNCH(2, 26, KP_DSTEPS_WIDE); }
         }
+#undef GCS_KP_LAUNCHW
 #undef GCS_KP_LAUNCH
         GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
         return GCS_OK;
