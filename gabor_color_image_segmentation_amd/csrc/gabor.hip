@@ -394,45 +394,67 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             if (oy < HL && ox < pitchL) {
                 const int by = oy >> side_sh, iy = oy & ((1 << side_sh) - 1);
                 const int bx0 = ox >> side_sh;
-                unsigned char *img_base = feats + (size_t)b * ntiles * tile_bytes + offL;
+                // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
+                // target block (tile of the block, block inside the tile, row inside the block, filter parity h), so that a
+                // store costs no vector address arithmetic (global_store with an SGPR base).
+                unsigned char *ubase = feats + (size_t)b * ntiles * tile_bytes + offL + (size_t)(c * FLv + fbase) * npl * 2;
+                const unsigned row_off = (unsigned)(((iy << side_sh) + h * npl) * 2);
+                auto lane_off = [&](int p) -> unsigned {           // block bx0 + p, this lane's row inside it
+                    const int blk = by * bx_n + bx0 + p;
+                    return (unsigned)(blk >> 2) * (unsigned)tile_bytes + (unsigned)((blk & 3) << (2 * side_sh)) * 2u + row_off;
+                };
+                auto planes = [&](auto &&put) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (mt == MT - 1 && g >= GLAST) continue;
-                        const int f = fbase + 8 * mt + 2 * g + h;      // filter index inside the level
-                        if (f >= FLv) continue;
-                        // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
-                        // signed MFMA digits for the k-means pass, which stages them untouched
-                        const unsigned w0 = outp[mt][g][0] ^ 0x80808080u, w1 = outp[mt][g][1] ^ 0x80808080u,
-                                       w2 = outp[mt][g][2] ^ 0x80808080u, w3 = outp[mt][g][3] ^ 0x80808080u;
-                        const size_t plane_off = (size_t)(c * FLv + f) * npl * 2 + (size_t)(iy << side_sh) * 2;
-                        auto dst = [&](int p) -> unsigned char * {     // block bx0 + p, this lane's row inside it
-                            const int blk = by * bx_n + bx0 + p;
-                            return img_base + (size_t)(blk >> 2) * tile_bytes + plane_off +
-                                   (size_t)((blk & 3) << (2 * side_sh)) * 2;
-                        };
-                        if (L == 0) {
-                            // nontemporal: the slab (0.9 GB per 64 images) is read back only by the Lloyd passes; plain stores
-                            // leave ~0.3 GB of it dirty in L2 / Infinity Cache and the first pass then shares HBM with their
-                            // write-back (same-box A/B: first pass 0.219 -> 0.186 ms, step -2 %)
-                            __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(dst(0)));
-                        } else if (L == 1) {
-                            __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(dst(0)));
-                            if (bx0 + 1 < bx_n) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(dst(1)));
-                        } else if (L == 2) {
-                            const unsigned w[4] = {w0, w1, w2, w3};
-#pragma unroll
-                            for (int p = 0; p < 4; ++p)
-                                if (bx0 + p < bx_n) *reinterpret_cast<unsigned *>(dst(p)) = w[p];
-                        } else {
-                            const unsigned w[4] = {w0, w1, w2, w3};
-#pragma unroll
-                            for (int p = 0; p < 8; ++p)
-                                if (bx0 + p < bx_n)
-                                    *reinterpret_cast<uint16_t *>(dst(p)) = (uint16_t)(w[p >> 1] >> (16 * (p & 1)));
+                        for (int g = 0; g < 4; ++g) {
+                            if (mt == MT - 1 && g >= GLAST) continue;
+                            // an odd filter count leaves the h = 1 half of the LAST pair without a filter
+                            const bool last = mt == MT - 1 && g == GLAST - 1;
+                            if (last && fbase + 8 * mt + 2 * g + h >= FLv) continue;
+                            // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
+                            // signed MFMA digits for the k-means pass, which stages them untouched
+                            put(ubase + (size_t)(8 * mt + 2 * g) * npl * 2, outp[mt][g][0] ^ 0x80808080u,
+                                outp[mt][g][1] ^ 0x80808080u, outp[mt][g][2] ^ 0x80808080u, outp[mt][g][3] ^ 0x80808080u);
                         }
-                    }
+                };
+                if (L == 0) {
+                    // nontemporal: the slab (0.9 GB per 64 images) is read back only by the Lloyd passes; plain stores
+                    // leave ~0.3 GB of it dirty in L2 / Infinity Cache and the first pass then shares HBM with their
+                    // write-back (same-box A/B: first pass 0.219 -> 0.186 ms, step -2 %)
+                    const unsigned o0 = lane_off(0);
+                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
+                    });
+                } else if (L == 1) {
+                    const unsigned o0 = lane_off(0), o1 = lane_off(1);
+                    const bool has1 = bx0 + 1 < bx_n;
+                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o0));
+                        if (has1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o1));
+                    });
+                } else if (L == 2) {
+                    unsigned o[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) o[p] = lane_off(p);
+                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            if (bx0 + p < bx_n) *reinterpret_cast<unsigned *>(up + o[p]) = w[p];
+                    });
+                } else {
+                    unsigned o[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) o[p] = lane_off(p);
+                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        const unsigned w[4] = {w0, w1, w2, w3};
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if (bx0 + p < bx_n)
+                                *reinterpret_cast<uint16_t *>(up + o[p]) = (uint16_t)(w[p >> 1] >> (16 * (p & 1)));
+                    });
+                }
             }
         }
     }
@@ -493,6 +515,8 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     if (!gcs_make_layout(H, W, n_scales, n_orient, &lo))
         return gcs_fail(GCS_EINVAL, "gcs_gabor_features: need 1 <= n_scales <= 8, n_orient >= 1");
     if ((long long)B * lo.ntiles * lo.tile_bytes > 0x7fffffffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: slab too large");
+    if ((long long)lo.ntiles * lo.tile_bytes > 0xffffffffLL)   // the kernel addresses one image's slab with 32-bit lane offsets
+        return gcs_fail(GCS_EINVAL, "gcs_gabor_features: one image's feature slab must stay below 4 GiB");
     const GaborWs ws = gabor_ws(B, H, W, lo.n_levels);
     if (ws.Hp[0] / 4 + 1 > 65535) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: H too large for one launch");
     if ((size_t)W * 6 + 16 > 60 * 1024) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: W too large for the pyramid row buffer");
