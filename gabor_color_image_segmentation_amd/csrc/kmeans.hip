@@ -265,7 +265,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     const int D = lo.D;
     const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
     const int ntiles = lo.ntiles;
-    const unsigned char *fb = feats + (size_t)b * ntiles * lo.tile_bytes;   // this image's tiles, each one contiguous run
+    // The tile list this workgroup strides through. Per-image codebooks: the tiles of image b, stride `parts`. One
+    // global codebook: the tiles of the WHOLE batch as one list, stride B * parts: at any moment the resident workgroups
+    // then read one contiguous window of the slab (B * parts tiles, 17 MB) instead of B separate ones, which is what
+    // HBM's channel / bank interleave is built for (same box: pass 0.190 -> 0.175 ms; profiles/r2_notes.md).
+    const int nimg = per_image ? 1 : (int)gridDim.y;
+    const int G = parts * nimg, g = per_image ? part : b * parts + part;
+    const int nlist = ntiles * nimg;
+    const size_t img0 = per_image ? (size_t)b * ntiles : 0;               // first tile of the list in the slab
+    const unsigned char *fb = feats + img0 * lo.tile_bytes;               // each tile one contiguous run
+    uint8_t *lb = labels + img0 * KP_TP;
 
     // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16 in PHYSICAL
     //      plane order, stored offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D.
@@ -433,37 +442,40 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     const unsigned eqr = (unsigned)un * 0x01010101u;
     const int cnt_bp = 2 * D;
 
-    // Sweep order: workgroup `part` takes logical tiles part, part+parts, ...; on odd passes the physical
-    // order is reversed (boustrophedon), so a pass starts on the tiles the previous pass read last, i.e. on
-    // what is still in the 256 MiB Infinity Cache.
-    auto phys = [&](int lt) { return reverse ? ntiles - 1 - lt : lt; };
-    int ltile = part;
-    if (ltile < ntiles) stage_load(phys(ltile));
-    // this wave's block (one 8x8 block per wave) as (block row, block column), advanced by 4 * parts blocks per step
-    // without a division: which pixels exist and vote is decided from it
-    const int bstep = 4 * parts;
-    const int step_q = __builtin_amdgcn_readfirstlane(bstep / lo.bx_n), step_r = bstep - step_q * lo.bx_n;
+    // Sweep order: workgroup g takes list positions g, g+G, ...; on odd passes the physical order is reversed
+    // (boustrophedon), so a pass starts on the tiles the previous pass read last, i.e. on what is still in the 256 MiB
+    // Infinity Cache.
+    auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
+    int ltile = g;
+    if (ltile < nlist) stage_load(phys(ltile));
+    // this wave's block (one 8x8 block per wave) as (block row, block column) inside ITS image, advanced without a
+    // division: which pixels exist and vote is decided from it. A step moves the tile index inside the image by
+    // s1 = G mod ntiles, or by s1 - ntiles when that runs past the image's last tile (global list only).
+    const int s1 = __builtin_amdgcn_readfirstlane(G % ntiles);
+    const int q1 = __builtin_amdgcn_readfirstlane(4 * s1 / lo.bx_n), r1 = 4 * s1 - q1 * lo.bx_n;
+    const int q2 = __builtin_amdgcn_readfirstlane(4 * (ntiles - s1) / lo.bx_n), r2 = 4 * (ntiles - s1) - q2 * lo.bx_n;
+    int tin = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) % ntiles);   // tile index inside its image
     int by, bx;
     {
-        const int blk0 = __builtin_amdgcn_readfirstlane(4 * phys(part < ntiles ? part : 0) + wave);
+        const int blk0 = 4 * tin + wave;
         by = blk0 / lo.bx_n;
         bx = blk0 - by * lo.bx_n;
     }
-    for (; ltile < ntiles; ltile += parts) {
+    for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
         stage_write();
         __syncthreads();
         // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
         // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
         __builtin_amdgcn_s_setprio(3);
-        if (ltile + parts < ntiles) stage_load(phys(ltile + parts));   // in flight during the MFMAs
+        if (ltile + G < nlist) stage_load(phys(ltile + G));   // in flight during the MFMAs
         __builtin_amdgcn_s_setprio(0);
         if (lo.n_levels > 2) {
             expand_deep();
             __syncthreads();
         }
 
-        const int blk = 4 * tile + wave;
+        const int blk = 4 * tin + wave;                          // block index inside the image
         // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
 #pragma unroll
         for (int sub_i = 0; sub_i < (WAVES == 8 ? 1 : 2); ++sub_i) {
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 const int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7);
                 const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
-                labels[((size_t)b * ntiles + tile) * KP_TP + pl] = (uint8_t)bj;
+                lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
             }
         }
         if (WAVES == 8) __syncthreads();                       // the block's labels come from two waves
@@ -558,14 +570,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 accu[nti] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[nti], 0, 0, 0);
             }
         }
-        if (reverse) {                                           // next block of this wave: 4 * parts blocks back / on
-            bx -= step_r;
-            by -= step_q;
-            if (bx < 0) { bx += lo.bx_n; --by; }
-        } else {
-            bx += step_r;
-            by += step_q;
-            if (bx >= lo.bx_n) { bx -= lo.bx_n; ++by; }
+        {                                                        // next tile of this workgroup: s1 tiles on / back, modulo the image
+            const int tn = reverse ? tin - s1 : tin + s1;
+            const bool wrap = reverse ? tn < 0 : tn >= ntiles;
+            const bool up = reverse == wrap;                     // block index grows
+            const int dq = wrap ? q2 : q1, dr = wrap ? r2 : r1;
+            tin = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
+            if (up) {
+                bx += dr;
+                by += dq;
+                if (bx >= lo.bx_n) { bx -= lo.bx_n; ++by; }
+            } else {
+                bx -= dr;
+                by -= dq;
+                if (bx < 0) { bx += lo.bx_n; --by; }
+            }
         }
         __syncthreads();
     }
@@ -637,6 +656,8 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
         return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: need 0 <= row_lo < row_hi <= H");
     if (B > 65535) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: B too large for one launch");
+    if ((long long)B * lo.ntiles > 0x1fffffffLL)   // 4 * (tile index in the batch list) is kept in an int
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: batch too large for one launch");
     if (k < 1 || k > GCS_K_MAX) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: k must be in 1..16");
     if (n_sets != 1 && n_sets != B)
         return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: n_sets must be 1 or B");
