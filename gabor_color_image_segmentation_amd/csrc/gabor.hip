@@ -233,15 +233,29 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
 #endif
 constexpr int GCS_GABOR_MTMAX = GCS_GABOR_MTMAX_;   // row tiles per launch
 
-// One pyramid level. MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that
-// exist in the last row tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
+// One pyramid level of a launch. Consecutive levels with the same filter count share ONE launch (tiles of level L, then
+// L+1, ... in one list): a level boundary then costs one reload of the A operand per workgroup instead of a kernel
+// boundary (drain + ramp of 512 persistent workgroups, and a launch for a one-image call).
+struct GaborLevel {
+    const int8_t *planes;    // padded planes [B][3][Hp][Wp]
+    const int8_t *apack;     // packed taps of this launch's row tiles
+    const int32_t *bias;
+    int HL, Hp, Wp, pitchL, tiles_x, tiles_per_image;
+    int tile_end;            // end of this level's tiles in the launch's tile list
+    int L, offL;
+};
+struct GaborLevels {
+    GaborLevel lv[GCS_LEVELS_MAX];
+};
+
+// MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that exist in the last row
+// tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
 // KS = K-steps of 2 tap rows: 8 for a 15-row frame, 7 when ksize <= 13 (its rows 1..13 of the frame: the last K-step
 // would multiply zeros).
 template <int MT, int GLAST, int KS>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
-    const int8_t *__restrict__ planes, int HL, int Hp, int Wp, const int8_t *__restrict__ apack,
-    const int32_t *__restrict__ bias, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int pitchL,
-    int tiles_x, int tiles_per_image, int total_tiles, int L, int bx_n, int ntiles, int tile_bytes, int offL) {
+    GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, int bx_n, int ntiles,
+    int tile_bytes) {
     // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
     // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
     // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
@@ -253,17 +267,29 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    auto stage_tile = [&](int tile, int buf) {
-        const int b_ = tile / tiles_per_image, rem = tile % tiles_per_image;
-        const int y0_ = (rem / tiles_x) * G_TH, x0_ = (rem % tiles_x) * G_TW;
-        const int8_t *src0 = planes + ((size_t)b_ * 3 * Hp + y0_) * Wp + x0_;
+    // level of a tile of the list (uniform; a workgroup's tiles only move up the levels). Selected field by field: a
+    // dynamically indexed by-value kernel argument would be copied to scratch.
+    auto level_of = [&](int tile, int from) {
+        int l = from;
+        while (l + 1 < GCS_LEVELS_MAX && tile >= (l == 0 ? G.lv[0].tile_end : l == 1 ? G.lv[1].tile_end : G.lv[2].tile_end)) ++l;
+        return l;
+    };
+    auto pick = [&](int l) -> GaborLevel { return l == 0 ? G.lv[0] : l == 1 ? G.lv[1] : l == 2 ? G.lv[2] : G.lv[3]; };
+    static_assert(GCS_LEVELS_MAX == 4, "level_of / pick enumerate four levels");
+
+    auto stage_tile = [&](int tile, int lvl, int buf) {
+        const GaborLevel v = pick(lvl);
+        const int t_ = tile - (lvl ? pick(lvl - 1).tile_end : 0);
+        const int b_ = t_ / v.tiles_per_image, rem = t_ % v.tiles_per_image;
+        const int y0_ = (rem / v.tiles_x) * G_TH, x0_ = (rem % v.tiles_x) * G_TW;
+        const int8_t *src0 = v.planes + ((size_t)b_ * 3 * v.Hp + y0_) * v.Wp + x0_;
 #pragma unroll
         for (int k = 0; k < (NCHUNK + 255) / 256; ++k) {
             const int i = tid + 256 * k;
             if (i < NCHUNK) {
                 const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
                 const int row = rc % G_LROWS, c = rc / G_LROWS;
-                const int8_t *g = src0 + ((size_t)c * Hp + row) * Wp + 16 * ch16;
+                const int8_t *g = src0 + ((size_t)c * v.Hp + row) * v.Wp + 16 * ch16;
                 // LDS destination: wave-uniform base (this wave's first chunk) + lane * 16
                 int8_t *l = &s_tile[buf][0][0][0] + 16 * (256 * k + 64 * wave);
                 __builtin_amdgcn_global_load_lds(
@@ -273,14 +299,6 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         }
     };
 
-    // ---- the whole A operand lives in registers: MT x 8 lane-linear 16-byte fragments
-    v4i afr[MT][KS];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            afr[mt][kk] = reinterpret_cast<const v4i *>(apack)[((size_t)mt * 8 + kk) * 64 + lane];
-
     // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
     // for a pixel shift s = 4*qq + t in 0..7. A lane therefore ends up owning 8 consecutive
     // pixels (16 bytes) per filter: one row of an 8x8 block of the slab.
@@ -289,23 +307,46 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 
     int k256 = 256, k65536 = 65536;
     asm volatile("" : "+s"(k256), "+s"(k65536));      // opaque multipliers: keep v_mad_i32_i24 / v_mad_u32_u24, not shifts
-    int bias_v[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias_v[mt][g] = bias[8 * mt + 2 * g + h];
 
-    // slab geometry of this level (csrc/common.h): sub-block side 8 >> L, 2^L blocks under a lane's 8 pixels
-    const int side_sh = 3 - L;
-    const int npl = KP_TP >> (2 * L);               // pixels per plane of a tile at this level
+    // ---- per level: the whole A operand lives in registers (MT x KS lane-linear 16-byte fragments) with the biases
+    v4i afr[MT][KS];
+    int bias_v[MT][4];
+    int HL = 0, pitchL = 0, tiles_x = 1, tiles_per_image = 1, tile0 = 0, L = 0, offL = 0;
+    int side_sh = 3, npl = KP_TP;          // slab geometry of the level (csrc/common.h): sub-block side 8 >> L, pixels per plane of a tile
+    auto enter_level = [&](int lvl) {
+        const GaborLevel v = pick(lvl);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                afr[mt][kk] = reinterpret_cast<const v4i *>(v.apack)[((size_t)mt * 8 + kk) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias_v[mt][g] = v.bias[8 * mt + 2 * g + h];
+        HL = v.HL; pitchL = v.pitchL; tiles_x = v.tiles_x; tiles_per_image = v.tiles_per_image;
+        tile0 = lvl ? pick(lvl - 1).tile_end : 0;
+        L = v.L; offL = v.offL;
+        side_sh = 3 - L;
+        npl = KP_TP >> (2 * L);
+    };
 
     int tile = blockIdx.x;
-    if (tile < total_tiles) stage_tile(tile, 0);
+    int lvl = -1, lvl_next = tile < total_tiles ? level_of(tile, 0) : 0;
+    if (tile < total_tiles) stage_tile(tile, lvl_next, 0);
     __syncthreads();                       // drains the LDS-DMA (vmcnt) and orders it for every wave
     for (int it = 0; tile < total_tiles; tile += gridDim.x, ++it) {
       const int buf = it & 1;
-      if (tile + (int)gridDim.x < total_tiles) stage_tile(tile + gridDim.x, buf ^ 1);
-      const int b = tile / tiles_per_image, trem = tile % tiles_per_image;
+      if (lvl_next != lvl) {
+          lvl = lvl_next;
+          enter_level(lvl);
+      }
+      if (tile + (int)gridDim.x < total_tiles) {
+          lvl_next = level_of(tile + gridDim.x, lvl);
+          stage_tile(tile + gridDim.x, lvl_next, buf ^ 1);
+      }
+      const int tl = tile - tile0;
+      const int b = tl / tiles_per_image, trem = tl % tiles_per_image;
       const int y0 = (trem / tiles_x) * G_TH, x0 = (trem % tiles_x) * G_TW;
       if (y0 + wave * 8 < HL) {            // waves wholly below the image skip the work, not the barrier
     for (int c = 0; c < 3; ++c) {
@@ -522,7 +563,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     if ((size_t)W * 6 + 16 > 60 * 1024) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: W too large for the pyramid row buffer");
     unsigned char *wsb = static_cast<unsigned char *>(workspace);
     const dim3 block(256);
-    int mt_base = 0;
+    // ---- pre-passes: the padded planes of every level (level L >= 2 reads level L-1's compact image)
     for (int L = 0; L < lo.n_levels; ++L) {
         int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
         const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
@@ -543,27 +584,52 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                                planes, img_out);
         }
         GCS_CHECK_LAUNCH("gcs_gabor_features(pad)");
-        const int tiles_x = (WL + G_TW - 1) / G_TW, tiles_y = (HL + G_TH - 1) / G_TH;
-        const int tiles_per_image = tiles_x * tiles_y;
-        const long long total_ll = (long long)tiles_per_image * B;
-        if (total_ll > 0x7fffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
-        const int total_tiles = (int)total_ll;
-        const int pitchL = round_up(WL, 8);
-        const int MT = mtiles(lo.FL[L]);
+    }
+    // ---- the bank: one launch per run of levels with the same filter count (every level of an even-scale bank)
+    int mt_base[GCS_LEVELS_MAX];
+    for (int L = 0, m = 0; L < lo.n_levels; ++L) {
+        mt_base[L] = m;
+        m += mtiles(lo.FL[L]);
+    }
+    for (int L0 = 0; L0 < lo.n_levels;) {
+        int L1 = L0 + 1;
+        while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
+        const int FLg = lo.FL[L0], MT = mtiles(FLg);
         for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
             const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
-            // filters of this launch: [8*mt0, min(FL, 8*(mt0+n))) of the level (planes c*FL + f)
-            const int fl_here = lo.FL[L] - 8 * mt0 < 8 * n ? lo.FL[L] - 8 * mt0 : 8 * n;
+            // filters of this launch: [8*mt0, min(FL, 8*(mt0+n))) of each level (planes c*FL + f)
+            const int fl_here = FLg - 8 * mt0 < 8 * n ? FLg - 8 * mt0 : 8 * n;
             const int glast = (fl_here - 8 * (n - 1) + 1) / 2;
+            GaborLevels G{};
+            long long total_ll = 0;
+            for (int L = L0; L < L1; ++L) {
+                GaborLevel &v = G.lv[L - L0];
+                v.planes = reinterpret_cast<const int8_t *>(wsb + ws.plane_off[L]);
+                v.apack = packed + (size_t)(mt_base[L] + mt0) * 8 * 64 * 16;
+                v.bias = bias + (size_t)(mt_base[L] + mt0) * 8;
+                v.HL = ws.HL[L];
+                v.Hp = ws.Hp[L];
+                v.Wp = ws.Wp[L];
+                v.pitchL = round_up(ws.WL[L], 8);
+                v.tiles_x = (ws.WL[L] + G_TW - 1) / G_TW;
+                v.tiles_per_image = v.tiles_x * ((ws.HL[L] + G_TH - 1) / G_TH);
+                total_ll += (long long)v.tiles_per_image * B;
+                if (total_ll > 0x3fffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
+                v.tile_end = (int)total_ll;
+                v.L = L;
+                v.offL = lo.off[L];
+            }
+            for (int i = L1 - L0; i < GCS_LEVELS_MAX; ++i) {      // unused entries: never selected (tile < total_tiles)
+                G.lv[i] = G.lv[L1 - L0 - 1];
+                G.lv[i].tile_end = 0x7fffffff;
+            }
+            const int total_tiles = (int)total_ll;
             // persistent grid: one workgroup per resident slot (2 per CU at MT >= 2, 3 at MT == 1)
             const int slots = 256 * (n == 1 ? 3 : 2);
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
-            const int8_t *ap = packed + (size_t)(mt_base + mt0) * 8 * 64 * 16;
-            const int32_t *bp = bias + (size_t)(mt_base + mt0) * 8;
 #define GCS_GABOR_LAUNCH3(MT_, GL_, KS_)                                                                                 \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_>), grid, block, 0, stream, planes, HL, Hp, Wp, ap, bp,        \
-                       lo.FL[L], 8 * mt0, shift, reinterpret_cast<unsigned char *>(feats), pitchL, tiles_x,               \
-                       tiles_per_image, total_tiles, L, lo.bx_n, lo.ntiles, lo.tile_bytes, lo.off[L])
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_>), grid, block, 0, stream, G, FLg, 8 * mt0, shift,              \
+                       reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
             // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
 #define GCS_GABOR_LAUNCH(MT_, GL_)                                   \
     do {                                                             \
@@ -589,7 +655,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
 #undef GCS_GABOR_LAUNCH
             GCS_CHECK_LAUNCH("gcs_gabor_features");
         }
-        mt_base += MT;
+        L0 = L1;
     }
     return GCS_OK;
 }

@@ -112,6 +112,20 @@ def test_images_narrower_than_a_kmeans_tile(torch_cuda):
     assert np.array_equal(got, so.segment_batch(imgs, mode="global", k=4, n_iter=3))
 
 
+@pytest.mark.parametrize("b,h,w", [(24, 100, 120), (3, 300, 500), (7, 161, 241)])
+def test_global_codebook_batch_list_walk(torch_cuda, b, h, w):
+    """One global codebook: the pass walks the tiles of the whole batch as ONE list (stride = all workgroups) and tracks
+    the tile index inside its image without a division; a stride crosses image boundaries once or several times
+    (49, 599 and 164 tiles per image against 768 workgroups). Forward and reverse sweeps (4 passes) against the C oracle."""
+    from oracle import c_oracle as co
+    from gabor_color_image_segmentation_amd import Segmenter
+    imgs = _synth(b, h, w, seed=77 + b)
+    seg = Segmenter(k=5, n_iter=4)
+    got = seg.segment_batch(imgs, mode="global")
+    ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, seg.bank.n_orient, k=5, n_iter=4, mode="global")
+    assert np.array_equal(got, ref)
+
+
 def test_randomised_shapes_banks_and_codebooks(torch_cuda):
     """40 seeded random cases against the C oracle: image sizes from the 8x8 minimum to a few tiles (odd widths,
     widths below one Gabor / k-means tile, heights that leave waves idle), banks F = 1..30 with every odd ksize,
