@@ -252,7 +252,9 @@ struct GaborLevels {
 // tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
 // KS = K-steps of 2 tap rows: 8 for a 15-row frame, 7 when ksize <= 13 (its rows 1..13 of the frame: the last K-step
 // would multiply zeros).
-template <int MT, int GLAST, int KS>
+// FUSED = the tile list holds more than one level (otherwise every level field is a loop-invariant kernel argument:
+// same-box A/B, default bank, separate launches: 0.552 ms with the fields fixed, 0.566 ms with them reloaded per level).
+template <int MT, int GLAST, int KS, bool FUSED>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, int bx_n, int ntiles,
     int tile_bytes) {
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     // level of a tile of the list (uniform; a workgroup's tiles only move up the levels). Selected field by field: a
     // dynamically indexed by-value kernel argument would be copied to scratch.
     auto level_of = [&](int tile, int from) {
+        if constexpr (!FUSED) return 0;
         int l = from;
         while (l + 1 < GCS_LEVELS_MAX && tile >= (l == 0 ? G.lv[0].tile_end : l == 1 ? G.lv[1].tile_end : G.lv[2].tile_end)) ++l;
         return l;
@@ -332,14 +335,17 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     };
 
     int tile = blockIdx.x;
-    int lvl = -1, lvl_next = tile < total_tiles ? level_of(tile, 0) : 0;
+    int lvl = FUSED ? -1 : 0, lvl_next = tile < total_tiles ? level_of(tile, 0) : 0;
+    if constexpr (!FUSED) enter_level(0);
     if (tile < total_tiles) stage_tile(tile, lvl_next, 0);
     __syncthreads();                       // drains the LDS-DMA (vmcnt) and orders it for every wave
     for (int it = 0; tile < total_tiles; tile += gridDim.x, ++it) {
       const int buf = it & 1;
-      if (lvl_next != lvl) {
-          lvl = lvl_next;
-          enter_level(lvl);
+      if constexpr (FUSED) {
+          if (lvl_next != lvl) {
+              lvl = lvl_next;
+              enter_level(lvl);
+          }
       }
       if (tile + (int)gridDim.x < total_tiles) {
           lvl_next = level_of(tile + gridDim.x, lvl);
@@ -593,7 +599,10 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     }
     for (int L0 = 0; L0 < lo.n_levels;) {
         int L1 = L0 + 1;
-        while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
+        // fused lists pay ~2 % for level fields that are no longer launch constants and win the small levels' ramp and
+        // tail back: a gain from three levels on (8x8 bank: 0.90 -> 0.80 ms), a small loss for two (0.552 -> 0.557 ms)
+        if (lo.n_levels > 2)
+            while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
         const int FLg = lo.FL[L0], MT = mtiles(FLg);
         for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
             const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
@@ -627,9 +636,14 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             // persistent grid: one workgroup per resident slot (2 per CU at MT >= 2, 3 at MT == 1)
             const int slots = 256 * (n == 1 ? 3 : 2);
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
-#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_)                                                                                 \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_>), grid, block, 0, stream, G, FLg, 8 * mt0, shift,              \
+#define GCS_GABOR_LAUNCH4(MT_, GL_, KS_, FU_)                                                                            \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_, FU_>), grid, block, 0, stream, G, FLg, 8 * mt0, shift,         \
                        reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
+#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_)                             \
+    do {                                                             \
+        if (L1 - L0 > 1) GCS_GABOR_LAUNCH4(MT_, GL_, KS_, true);     \
+        else GCS_GABOR_LAUNCH4(MT_, GL_, KS_, false);                \
+    } while (0)
             // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
 #define GCS_GABOR_LAUNCH(MT_, GL_)                                   \
     do {                                                             \
@@ -651,6 +665,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 default: GCS_GABOR_LAUNCH(1, 4); break;
                 }
             }
+#undef GCS_GABOR_LAUNCH4
 #undef GCS_GABOR_LAUNCH3
 #undef GCS_GABOR_LAUNCH
             GCS_CHECK_LAUNCH("gcs_gabor_features");
