@@ -3,8 +3,8 @@
 // The reference ships no code for this path; slot: /root/reference/BSD_metrics/script.py:30.
 //
 // Kernels
-//   gabor_plane_kernel      level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised;
-//                           level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
+//   gabor_plane_kernel      level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised.
+//   gabor_down_kernel       level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
 //                           padded plane of level L and, when a further level follows, as a compact image.
 //   gabor_mfma_kernel       one pyramid level: A = packed 2-digit int8 taps of the level's filters (rows = filter x
 //                           {re_lo,re_hi,im_lo,im_hi}, resident in registers), B = (pixel-128) windows built from an LDS
@@ -66,97 +66,72 @@ extern "C" int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_
     return GCS_OK;
 }
 
-// Pre-passes. A thread produces 4 consecutive bytes of one padded plane row for the three channels:
-//   MODE 0  level 0: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128 (interleaved uint8 RGB -> planar int8 with
-//           the reflect border and the tile over-read materialised, so the main kernel stages tiles as aligned 16-byte
-//           copies with no index arithmetic);
-//   MODE 1  level 1 from the interleaved input, MODE 2 level L > 1 from the compact planar level L-1 image
-//           [B][3][Hs][Ws]: I_L[y][x] = (sum of the 2x2 block of I_{L-1}, indices clamped to the last row / column,
-//           + 2) >> 2 (SPEC.md §3 pyramid), evaluated at the reflected coordinates of the padded plane; `img_out` (may be
-//           NULL) receives the compact planar I_L for the next level.
-// Away from the borders the 4 pixels are 12 (MODE 0) or 2 x 24 (MODE 1) contiguous source bytes: they are fetched with
-// unaligned dword loads (gfx950 global memory takes any byte alignment) instead of one byte load per sample.
+// Level-0 pre-pass. A thread produces 4 consecutive bytes of GP_ROWS consecutive padded plane rows for the three channels:
+//   plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128 (interleaved uint8 RGB -> planar int8 with the reflect
+//   border and the tile over-read materialised, so the main kernel stages tiles as aligned 16-byte copies with no index
+//   arithmetic).
+// Away from the borders the 4 pixels are 12 contiguous source bytes: they are fetched with unaligned dword loads (gfx950
+// global memory takes any byte alignment) and de-interleaved with v_perm_b32 (3 per channel dword).
 typedef unsigned __attribute__((aligned(1))) unaligned_u32;
 
-__device__ __forceinline__ unsigned byte_of(const unsigned (&d)[6], int i) {   // byte i of a little-endian dword run
-    return (d[i >> 2] >> (8 * (i & 3))) & 255u;
-}
+constexpr int GP_ROWS = 4;   // plane rows per thread: their loads are issued together (the kernel is latency-bound)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
                                                           int Hp, int Wp, int8_t *__restrict__ planes,
                                                           uint8_t *__restrict__ img_out) {
+    static_assert(MODE == 0, "levels >= 1 use gabor_down_kernel");
     const int b = blockIdx.z;
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);               // 4 plane rows per workgroup, 64 threads each
-    if (r >= Hp) return;
-    const int ly = reflect(r - G_HALO, HL);
-    const int y0 = MODE == 0 ? ly : 2 * ly, y1 = MODE == 0 ? ly : min(2 * ly + 1, Hs - 1);
-    const bool row_in = r >= G_HALO && r - G_HALO < HL;
+    const int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * GP_ROWS;   // GP_ROWS consecutive plane rows per thread
+    if (r0 >= Hp) return;
     for (int u4 = blockIdx.x * 64 + (threadIdx.x & 63); u4 < Wp / 4; u4 += gridDim.x * 64) {
-        unsigned o[3] = {0u, 0u, 0u};
         const int l0 = 4 * u4 - G_HALO;                              // level column of this thread's first byte
-        const bool interior = l0 >= 0 && l0 + 3 < WL && (MODE == 0 || 2 * (l0 + 3) + 1 < Ws);
-        if (MODE != 2 && interior) {
-            unsigned m[3][4];
-            if (MODE == 0) {
-                const uint8_t *p = src + (((size_t)b * Hs + y0) * Ws + l0) * 3;
-                unsigned d[6];
+        const bool interior = l0 >= 0 && l0 + 3 < WL;
+        unsigned o[GP_ROWS][3];
+        if (interior) {
+            // 4 pixels = 12 contiguous source bytes per row, fetched with unaligned dword loads
+            unsigned d[GP_ROWS][3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = *reinterpret_cast<const unaligned_u32 *>(p + 4 * i);
+            for (int j = 0; j < GP_ROWS; ++j) {
+                const int ly = reflect(min(r0 + j, Hp - 1) - G_HALO, HL);
+                const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + l0) * 3;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) m[c][e] = byte_of(d, 3 * e + c);
-            } else {
-                const uint8_t *p0 = src + (((size_t)b * Hs + y0) * Ws + 2 * l0) * 3;
-                const uint8_t *p1 = src + (((size_t)b * Hs + y1) * Ws + 2 * l0) * 3;
-                unsigned d0[6], d1[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    d0[i] = *reinterpret_cast<const unaligned_u32 *>(p0 + 4 * i);
-                    d1[i] = *reinterpret_cast<const unaligned_u32 *>(p1 + 4 * i);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        m[c][e] = (byte_of(d0, 6 * e + c) + byte_of(d0, 6 * e + 3 + c) + byte_of(d1, 6 * e + c) +
-                                   byte_of(d1, 6 * e + 3 + c) + 2u) >> 2;
+                for (int i = 0; i < 3; ++i) d[j][i] = *reinterpret_cast<const unaligned_u32 *>(p + 4 * i);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    o[c] |= (m[c][e] ^ 0x80u) << (8 * e);
-                    if (MODE != 0 && img_out && row_in)
-                        img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (l0 + e)] = (uint8_t)m[c][e];
-                }
+            for (int j = 0; j < GP_ROWS; ++j) {
+                // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> one dword per channel, then pixel - 128
+                const unsigned d0 = d[j][0], d1 = d[j][1], d2 = d[j][2];
+                const unsigned r01 = __builtin_amdgcn_perm(d1, d0, 0x07060300u);   // R0 R1 . .   (bytes 0, 3 of d0; 6, 7 unused)
+                const unsigned g01 = __builtin_amdgcn_perm(d1, d0, 0x07060401u);   // G0 G1 . .   (byte 1 of d0, byte 0 of d1)
+                const unsigned b01 = __builtin_amdgcn_perm(d1, d0, 0x07060502u);   // B0 B1 . .   (byte 2 of d0, byte 1 of d1)
+                o[j][0] = __builtin_amdgcn_perm(d2, d1, 0x05020000u);              // . . R2 R3   (byte 2 of d1, byte 1 of d2)
+                o[j][1] = __builtin_amdgcn_perm(d2, d1, 0x06030000u);              // . . G2 G3   (byte 3 of d1, byte 2 of d2)
+                o[j][2] = __builtin_amdgcn_perm(d2, d2, 0x03000000u);              // . . B2 B3   (bytes 0, 3 of d2)
+                o[j][0] = (__builtin_amdgcn_perm(o[j][0], r01, 0x07060100u)) ^ 0x80808080u;
+                o[j][1] = (__builtin_amdgcn_perm(o[j][1], g01, 0x07060100u)) ^ 0x80808080u;
+                o[j][2] = (__builtin_amdgcn_perm(o[j][2], b01, 0x07060100u)) ^ 0x80808080u;
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int u = 4 * u4 + e;
-                const int lx = reflect(u - G_HALO, WL);
-                const int x0 = MODE == 0 ? lx : 2 * lx, x1 = MODE == 0 ? lx : min(2 * lx + 1, Ws - 1);
+            for (int j = 0; j < GP_ROWS; ++j) {
+                const int ly = reflect(min(r0 + j, Hp - 1) - G_HALO, HL);
+                o[j][0] = o[j][1] = o[j][2] = 0u;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    unsigned m;
-                    if (MODE == 2) {
-                        const uint8_t *p0 = src + (((size_t)b * 3 + c) * Hs + y0) * Ws, *p1 = src + (((size_t)b * 3 + c) * Hs + y1) * Ws;
-                        m = (p0[x0] + p0[x1] + p1[x0] + p1[x1] + 2u) >> 2;
-                    } else {
-                        const uint8_t *p0 = src + ((size_t)b * Hs + y0) * Ws * 3 + c, *p1 = src + ((size_t)b * Hs + y1) * Ws * 3 + c;
-                        m = MODE == 0 ? p0[(size_t)x0 * 3]
-                                      : (p0[(size_t)x0 * 3] + p0[(size_t)x1 * 3] + p1[(size_t)x0 * 3] + p1[(size_t)x1 * 3] + 2u) >> 2;
-                    }
-                    o[c] |= (m ^ 0x80u) << (8 * e);
-                    if (MODE != 0 && img_out && row_in && u >= G_HALO && u - G_HALO < WL)
-                        img_out[(((size_t)b * 3 + c) * HL + (r - G_HALO)) * WL + (u - G_HALO)] = (uint8_t)m;
+                for (int e = 0; e < 4; ++e) {
+                    const int lx = reflect(4 * u4 + e - G_HALO, WL);
+                    const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + lx) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[j][c] |= ((unsigned)p[c] ^ 0x80u) << (8 * e);
                 }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
+        for (int j = 0; j < GP_ROWS; ++j)
+            if (r0 + j < Hp)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r0 + j) * Wp + 4 * u4) = o[j][c];
     }
 }
 
@@ -573,7 +548,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     for (int L = 0; L < lo.n_levels; ++L) {
         int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
         const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
-        const dim3 pgrid((Wp / 4 + 63) / 64, (Hp + 3) / 4, B);
+        const dim3 pgrid((Wp / 4 + 63) / 64, (Hp + 4 * GP_ROWS - 1) / (4 * GP_ROWS), B);
         uint8_t *img_out = (L >= 1 && L + 1 < lo.n_levels) ? wsb + ws.img_off[L] : nullptr;
         if (L == 0)
             hipLaunchKernelGGL((gabor_plane_kernel<0>), pgrid, block, 0, stream, img, H, W, HL, WL, Hp, Wp, planes,
