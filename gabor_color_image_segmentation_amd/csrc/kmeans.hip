@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
             }
             lab[p] = bj;
         }
-        {   // label slab: same pixel order as the feature slab (tile, block in tile, row, column)
+        if (labels) {   // label slab: same pixel order as the feature slab (tile, block in tile, row, column)
             const int blk = (y >> 3) * lo.bx_n + (x >> 3);
             uint8_t *lp = labels + ((size_t)b * lo.ntiles + (blk >> 2)) * KP_TP + (blk & 3) * 64 + (y & 7) * 8 + (x & 7);
             *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(lab[0] | (lab[1] << 8));
         }
         // accumulate (second pass over this thread's planes; L2-resident)
-        const bool rows_ok = y >= row_lo && y < row_hi;
+        const bool rows_ok = partials && y >= row_lo && y < row_hi;
         const bool v0 = rows_ok && x < W, v1 = rows_ok && x + 1 < W;
         if (v0) {
             unsigned *a_0 = acc + (size_t)lab[0] * D1 * R + rep;
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         }
     }
     __syncthreads();
+    if (!partials) return;
     for (int i = tid; i < K * D1; i += 256) {
         const int j = i / D1, e = i % D1;                   // e = logical feature (or D = count)
         const int pe = e < D ? gcs_plane_of_logical(lo, e) : D;
@@ -257,6 +258,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
 
+    // either output may be absent (host contract): labels == NULL on the passes whose assignment nobody reads (every
+    // pass but the last), partials == NULL on the last pass, whose sums nobody reads (no update phase, no fold)
+    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = tid >> 6;                                // 0 .. WAVES-1
     const int wave = wid & 3;                                // the block of the tile this wave works on
@@ -542,12 +546,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 const int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7);
                 const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
-                lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
+                if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
             }
         }
-        if (WAVES == 8) __syncthreads();                       // the block's labels come from two waves
+        if (WAVES == 8 && do_acc) __syncthreads();             // the block's labels come from two waves
         // -------- update: one-hot MFMA over the block's 64 pixels
-        {
+        if (do_acc) {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
             v4i oh;
 #pragma unroll
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         __syncthreads();
     }
 
+    if (!do_acc) return;
     // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row: every wave
     //      parks its registers in its own slice of the tile buffer (no zero-fill, no atomics), one barrier.
     constexpr int RW = KP_NT * 16;                            // byte-planes per cluster row
@@ -650,8 +655,8 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, con
 extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
                                             int n_scales, int n_orient, int k, int n_sets, int row_lo, int row_hi,
                                             int reverse, uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
-    if (!feats || !cent || !labels || !partials)
-        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer");
+    if (!feats || !cent || (!labels && !partials))
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer (labels and partials may not both be NULL)");
     LAYOUT_OR_FAIL(lo, "gcs_kmeans_assign_accumulate");
     if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
         return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: need 0 <= row_lo < row_hi <= H");

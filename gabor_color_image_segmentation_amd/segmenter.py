@@ -118,10 +118,13 @@ class HipOps:
 
     @_on_device
     def assign_accumulate(self, feats, cent, b, h, w, k, n_sets, labels, partials, rows=None, reverse=False):
+        """One Lloyd pass. ``labels=None``: the assignment is not stored (every pass but the last); ``partials=None``:
+        no sums are accumulated (the last pass)."""
         lo, hi = rows if rows is not None else (0, h)
         _lib.check(self.lib.gcs_kmeans_assign_accumulate(
             feats.data_ptr(), cent.data_ptr(), b, h, w, *self._bk, k, n_sets, lo, hi,
-            1 if reverse else 0, labels.data_ptr(), partials.data_ptr(), self._stream()),
+            1 if reverse else 0, None if labels is None else labels.data_ptr(),
+            None if partials is None else partials.data_ptr(), self._stream()),
             "gcs_kmeans_assign_accumulate")
 
     @_on_device
@@ -219,8 +222,11 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
     for t in range(n_iter):
         # alternate the sweep direction: a pass starts where the previous one ended (Infinity Cache reuse); the first
         # pass runs back to front because the Gabor stage, which has just written the slab, finished at its end
-        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels, partials, rows, reverse=not (t & 1) and not _NO_REVERSE)
-        if t < n_iter - 1:
+        # only the last pass's labels are read, and its sums are not: either output of the kernel is optional
+        last = t == n_iter - 1
+        ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels if last else None, None if last else partials, rows,
+                              reverse=not (t & 1) and not _NO_REVERSE)
+        if not last:
             if dist is None:
                 ops.reduce_finalize(partials, b, h, w, k, n_sets, sums, cent)
             else:

@@ -31,7 +31,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 12
+#define GCS_ABI_VERSION 13
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_SCALES_MAX 8  /* octave pyramid of at most 4 levels: scales 2L, 2L+1 run on level L (SPEC.md §2) */
@@ -100,7 +100,9 @@ int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int n_sc
  * Infinity Cache (results do not depend on it). labels_dev: label slab; partials_dev:
  * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). D <= 207 (every BASELINE bank) runs on
  * the matrix cores, wider feature vectors on a generic VALU pass; k <= GCS_K_MAX. The same n_sets must be passed
- * to the reduce call that follows (it selects the partial layout). */
+ * to the reduce call that follows (it selects the partial layout).
+ * Either output may be NULL (not both): labels_dev == NULL skips the label store (the passes whose assignment nobody
+ * reads: all but the last), partials_dev == NULL skips the sums (the last pass: assignment only). */
 int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B,
                                  int H, int W, int n_scales, int n_orient, int k, int n_sets, int row_lo,
                                  int row_hi, int reverse, uint8_t *labels_dev, uint64_t *partials_dev,

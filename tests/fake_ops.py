@@ -61,8 +61,10 @@ class OracleOps:
             sums[s, :, :-1] += sm
             sums[s, :, -1] += cnt
             labs.append(lab)
-        labels["lab"] = np.stack(labs)
-        partials["sums"] = sums
+        if labels is not None:
+            labels["lab"] = np.stack(labs)
+        if partials is not None:
+            partials["sums"] = sums
 
     def reduce(self, partials, b, h, w, k, n_sets, sums):
         sums.copy_(torch.from_numpy(partials["sums"]))

@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 12
+    assert lib.gcs_abi_version() == 13
 
 
 def test_no_torch_types_in_the_abi():
@@ -124,6 +124,8 @@ def test_device_entry_points_validate_before_launching(lib):
     assert lib.gcs_kmeans_init(one, 4, 16, 16, 4, 6, 8, 3, one, None) == 1              # n_sets not in {1,B}
     assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 0, 1, 0, 16, 0, one, one, None) == 1
     assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 8, 1, 4, 4, 0, one, one, None) == 1   # empty row window
+    assert lib.gcs_kmeans_assign_accumulate(one, one, 1, 16, 16, 4, 6, 8, 1, 0, 16, 0, None, None, None) == 1  # no output at all
+    assert b"both" in lib.gcs_last_error()
     assert lib.gcs_features_gather(one, 1, 16, 16, 4, 6, 0, one, one, None) == 1
     assert lib.gcs_kmeans_reduce(None, 1, 16, 16, 72, 8, 1, one, None) == 1
     assert lib.gcs_kmeans_finalize(one, 0, 8, 72, one, None) == 1

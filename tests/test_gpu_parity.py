@@ -126,6 +126,27 @@ def test_global_codebook_batch_list_walk(torch_cuda, b, h, w):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("ns,no", [(4, 6), (8, 8), (3, 23)])
+def test_lloyd_pass_with_one_output_only(torch_cuda, ns, no):
+    """`labels_dev == NULL` (passes whose assignment nobody reads) and `partials_dev == NULL` (the last pass) give the
+    same labels / the same partial sums as the call with both outputs: narrow, wide (8-wave) and generic pass."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    b, h, w = 3, 56, 88
+    imgs = torch.from_numpy(_synth(b, h, w, seed=12)).cuda()
+    seg = Segmenter(n_scales=ns, n_orient=no, k=6)
+    ws = seg._workspace(b, h, w, "global")
+    seg.ops.gabor_features(imgs, ws["feats"])
+    seg.ops.kmeans_init(ws["feats"], b, h, w, seg.k, 1, ws["cent"])
+    lab2, par2 = torch.full_like(ws["labels"], 255), torch.zeros_like(ws["partials"])
+    seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, ws["labels"], ws["partials"])
+    seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, lab2, None)
+    seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, None, par2)
+    torch.cuda.synchronize()
+    assert torch.equal(lab2, ws["labels"])
+    assert torch.equal(par2, ws["partials"])
+
+
 def test_randomised_shapes_banks_and_codebooks(torch_cuda):
     """40 seeded random cases against the C oracle: image sizes from the 8x8 minimum to a few tiles (odd widths,
     widths below one Gabor / k-means tile, heights that leave waves idle), banks F = 1..30 with every odd ksize,
