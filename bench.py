@@ -265,7 +265,7 @@ def main():
     lv = [(3 * min(2, bank.n_scales - 2 * L) * bank.n_orient, 4 ** L) for L in range(bank.n_levels)]
     feat_b = 2 * sum(d / q for d, q in lv)
     g_bytes = (3 + feat_b) * px                      # u8 RGB in + u16 pyramid features out
-    a_bytes = (feat_b + 1) * px                      # u16 pyramid features in + u8 label out, per Lloyd pass
+    a_bytes = (feat_b + 1 / args.n_iter) * px        # per Lloyd pass: u16 pyramid features in; the u8 labels are stored by the last pass only
     g_ops = sum(2 * bank.ksize ** 2 * (4 * d // 3) * 3 * px / q for d, q in lv)   # int8 MACs x2: 2 digits x {re,im} x F_L rows
     kernels = {
         "gabor_mfma_kernel": dict(launches=g_n, launches_per_step=1, avg_ms=round(g_ms, 4), alg_bytes=int(g_bytes),
@@ -291,8 +291,9 @@ def main():
         ka = kernels["kmeans_pass_mfma_kernel"]
         roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ka["hbm_frac"], traffic=None,
-                        alg_bytes_def="pyramid-resident: (2*sum_L D_L/4^L + 1) B/px = 91 for the 4x6 bank; the un-fused "
-                                      "(2D+1) = 145 B/px definition gives unfused_def_gbs",
+                        alg_bytes_def="pyramid-resident: 2*sum_L D_L/4^L B/px read by every pass + 1 B/px of labels stored by "
+                                      "the last one = 90.1 B/px per launch for the 4x6 bank, n_iter 10; the un-fused (2D+1) "
+                                      "= 145 B/px definition gives unfused_def_gbs",
                         unfused_def_gbs=ka["unfused_def_gbs"])
 
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
@@ -362,9 +363,9 @@ def main():
                     slab_placement_ms=[round(x, 4) for x in getattr(seg, "slab_placement_ms", [])],
                     # whole job against the HBM roof: Gabor + n_iter passes, pyramid-resident bytes per pixel (and the
                     # un-fused uint16 definition of SURVEY.md §8d beside it), per GPU
-                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * (feat_b + 1), 1),
-                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * (feat_b + 1)) * px * args.steps / dt / 1e9, 1),
-                                    hbm_frac=round(((3 + feat_b) + args.n_iter * (feat_b + 1)) * px * args.steps / dt / 1e9
+                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * feat_b + 1, 1),
+                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * feat_b + 1) * px * args.steps / dt / 1e9, 1),
+                                    hbm_frac=round(((3 + feat_b) + args.n_iter * feat_b + 1) * px * args.steps / dt / 1e9
                                                    / HBM_PEAK_GBS, 4),
                                     unfused_def_bytes_per_px=(3 + 2 * D) + args.n_iter * (2 * D + 1)),
                     **extra)
