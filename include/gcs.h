@@ -8,10 +8,13 @@
  * what a binding for that slot calls underneath; INTEGRATION.md shows the
  * ctypes stub. Arithmetic is defined by SPEC.md (exact integers).
  *
- * Conventions: every pointer named *_dev is device memory owned by the caller; nothing is
- * allocated, freed or synchronised here (graph-capture safe); work is enqueued on `stream`
- * (a hipStream_t; NULL = default stream). Return 0 on success, GCS_E* otherwise, with a
- * thread-local message in gcs_last_error(). Not thread-safe per buffer.
+ * Conventions: every pointer named *_dev is device memory owned by the caller; no device memory is
+ * allocated or freed and the host is never blocked here; work is ordered on `stream` (a hipStream_t; NULL = default
+ * stream): when a call returns, everything it enqueued precedes whatever the caller enqueues on `stream` next.
+ * gcs_gabor_features may run part of a large batch on a library-owned side stream (one per device, created on first
+ * use) between an event fork from and an event join back into `stream` — the pattern stream capture records as a
+ * graph. Return 0 on success, GCS_E* otherwise, with a thread-local message in gcs_last_error(). Not thread-safe per
+ * buffer.
  */
 #ifndef GCS_H
 #define GCS_H

@@ -147,6 +147,30 @@ def test_lloyd_pass_with_one_output_only(torch_cuda, ns, no):
     assert torch.equal(par2, ws["partials"])
 
 
+def test_step_replays_from_a_captured_graph(torch_cuda):
+    """The C ABI's stream contract (include/gcs.h): a whole step, including the side-stream fork / join inside
+    gcs_gabor_features (batch >= 2 Mpix), is captured as a HIP graph; replays on new inputs equal the eager result."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    b, h, w = 16, 321, 481
+    a = torch.from_numpy(_synth(b, h, w, seed=3)).cuda()
+    c = torch.from_numpy(_synth(b, h, w, seed=4)).cuda()
+    seg = Segmenter(n_iter=3)
+    want_a = seg.segment_device(a, mode="global").clone()       # also builds and places the workspace, outside the capture
+    want_c = seg.segment_device(c, mode="global").clone()
+    assert not torch.equal(want_a, want_c)
+    static_in = a.clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = seg.segment_device(static_in, mode="global")
+    for src, want in ((c, want_c), (a, want_a), (c, want_c)):
+        static_in.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, want)
+
+
 def test_randomised_shapes_banks_and_codebooks(torch_cuda):
     """40 seeded random cases against the C oracle: image sizes from the 8x8 minimum to a few tiles (odd widths,
     widths below one Gabor / k-means tile, heights that leave waves idle), banks F = 1..30 with every odd ksize,
