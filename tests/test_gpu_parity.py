@@ -171,6 +171,40 @@ def test_step_replays_from_a_captured_graph(torch_cuda):
         assert torch.equal(static_out, want)
 
 
+def test_two_threads_two_streams_share_the_side_stream(torch_cuda):
+    """gcs_gabor_features forks large batches onto ONE library-owned side stream per device with reused fork / join events:
+    two host threads driving their own plans on their own streams at the same time must still get their own results."""
+    import threading
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    b, h, w = 16, 321, 481
+    data = [torch.from_numpy(_synth(b, h, w, seed=20 + i)).cuda() for i in range(2)]
+    segs = [Segmenter(n_iter=2) for _ in range(2)]
+    want = [segs[i].segment_device(data[i], mode="global").clone() for i in range(2)]
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    out = segs[i].segment_device(data[i], mode="global")
+                got[i] = out.clone()
+            st.synchronize()
+        except Exception as e:                              # surfaced in the main thread below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(got[i], want[i])
+
+
 def test_randomised_shapes_banks_and_codebooks(torch_cuda):
     """40 seeded random cases against the C oracle: image sizes from the 8x8 minimum to a few tiles (odd widths,
     widths below one Gabor / k-means tile, heights that leave waves idle), banks F = 1..30 with every odd ksize,
