@@ -11,6 +11,7 @@
 //   kmeans_finalize / init / features_gather / labels_widen / labels_raster: small helpers.
 // Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
 #include "common.h"
+#include <type_traits>
 
 #define LAYOUT_OR_FAIL(lo, who)                                        \
     GcsLayout lo;                                                      \
@@ -626,6 +627,423 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// One Lloyd pass for DEEP banks (80 <= D <= 207 with at most 48 planes on every pyramid level, k <= 8: the 8x8 bank of
+// BASELINE config 4), every level consumed at its OWN resolution. The tile goes to LDS as it sits in HBM (32.6 KB for
+// the 8x8 bank) instead of being replicated to 208 full-resolution plane rows (106 KB), so two workgroups share a CU:
+//   assign:  per level L the partial scores S_L[(j,pat)][parent] = A_pat^L * X^L on v_mfma_i32_32x32x32_i8 (3 K-steps of
+//            16 planes per level; N = the block's 64 pixels, 16 / 4 / 1 parents). The key of SPEC.md §4 is linear in the
+//            planes: key_j(px) = base_j - 32 U - 2^21 R2 with U = R0 + 256 R1 and (U, R2) summed over the levels at the
+//            pixel's parents; the coarse (U, R2) pairs travel through a wave-private LDS table.
+//   update:  sums[j][plane of L] = cnt_L[j][parent] * X^L[parent][plane] on v_mfma_i32_16x16x64_i8, where cnt_L counts the
+//            voting pixels of label j under a parent (level 0: the one-hot digit -128 as in the other pass; coarse
+//            levels: small positive counts built from the one-hot bytes); n_j by v_bcnt.
+// Same tile list, sweep order, validity rules, outputs and partial layout as kmeans_pass_mfma_kernel.
+constexpr int NV_DL = 48, NV_KS = 3, NV_NT = 6;              // planes, assign K-steps, update plane tiles per level
+constexpr int NV_P0 = KP_TP * 2 + 64, NV_P1 = 128 + 32, NV_P2 = 32, NV_P3 = 8;   // LDS bytes per plane row of level L
+constexpr int NV_OFF1 = NV_DL * NV_P0, NV_OFF2 = NV_OFF1 + NV_DL * NV_P1, NV_OFF3 = NV_OFF2 + NV_DL * NV_P2;
+constexpr int NV_END = NV_OFF3 + NV_DL * NV_P3;
+constexpr int NV_TILE = NV_END + 512;                        // room for the over-reads of unused MFMA columns / planes
+constexpr int NV_NST = 8;                                    // 16-byte staging chunks per thread (tile <= 32 640 B)
+
+// B fragments by hardware transpose (see kmeans_pass_mfma_kernel): issue only; nv_wait() then waits once for everything
+template <int PITCH>
+__device__ __forceinline__ void nv_issue(unsigned addr, v2i (&fa)[NV_KS], v2i (&fb)[NV_KS]) {
+#pragma unroll
+    for (int kk = 0; kk < NV_KS; ++kk)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+                     "ds_read_b64_tr_b16 %1, %2 offset:%c3"
+                     : "=&v"(fa[kk]), "=&v"(fb[kk])
+                     : "v"(addr + kk * 16 * PITCH), "i"(4 * PITCH)
+                     : "memory");
+}
+__device__ __forceinline__ void nv_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i (&bfr)[NV_KS]) {
+#pragma unroll
+    for (int kk = 0; kk < NV_KS; ++kk) {
+        asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
+        bfr[kk] = v4i{fa[kk][0], fa[kk][1], fb[kk][0], fb[kk][1]};
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
+    const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
+    int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels,
+    uint64_t *__restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[NV_TILE];
+    __shared__ __attribute__((aligned(16))) int2 s_part[4][3][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
+    __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
+    __shared__ long long s_const[16];
+    __shared__ __attribute__((aligned(16))) v4i s_apat[4][NV_KS][64];   // assign A fragments per level (lane-linear; used once per tile)
+    __shared__ int s_cnt[4][4][16];                                     // [wave][pixel group][cluster] voting pixels
+    __shared__ long long s_nj[16];
+
+    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // grid (B, parts): workgroups are dispatched part-major, so the parts_eff * B working ones are the first to start
+    const int b = blockIdx.x, part = blockIdx.y, nb = (int)gridDim.x;
+    const int D = lo.D, D1 = D + 1;
+    const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
+    const int ntiles = lo.ntiles;
+    const bool working = part < parts_eff;                   // 2 workgroups per CU are resident: the others only emit zeros
+    const int nimg = per_image ? 1 : nb;
+    const int G = parts_eff * nimg, g = per_image ? part : part * nb + b;
+    const int nlist = ntiles * nimg;
+    const size_t img0 = per_image ? (size_t)b * ntiles : 0;
+    const unsigned char *fb = feats + img0 * lo.tile_bytes;
+    uint8_t *lb = labels + img0 * KP_TP;
+
+    // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists
+    uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
+    for (int i = tid; i < 8 * 4 * NV_DL; i += 256) {
+        const int j = i / (4 * NV_DL), L = (i / NV_DL) & 3, pl = i % NV_DL;
+        const bool ok = j < K && L < NL && pl < lo.DL[L];
+        cs[i] = ok ? (uint16_t)(cset[j * D + gcs_logical_of_plane(lo, lo.row0[L] + pl)] ^ 0x8080u) : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int j = tid >> 4; j < 16; j += 16) {                // key base, as in kmeans_pass_mfma_kernel
+        const int sub = tid & 15;
+        long long nrm = 0, scl = 0, sch = 0;
+        if (j < K && j < 8)
+            for (int d = sub; d < 4 * NV_DL; d += 16) {
+                const int L = d / NV_DL, pl = d % NV_DL;
+                if (L < NL && pl < lo.DL[L]) {
+                    const long long c = cs[j * 4 * NV_DL + d] ^ 0x8080u;
+                    nrm += c * c;
+                    scl += c & 255;
+                    sch += c >> 8;
+                }
+            }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            nrm += __shfl_xor(nrm, m);
+            scl += __shfl_xor(scl, m);
+            sch += __shfl_xor(sch, m);
+        }
+        if (sub == 0) {
+            const long long q = 16384LL * D;
+            const long long gg = (128 * scl - q) + 256 * (128 * (sch + scl) - 2 * q) + 65536 * (128 * sch - q);
+            s_const[j] = j < K ? 16 * (nrm - 2 * gg) + j : (1LL << 62) + j;
+        }
+    }
+    // ---- assign A fragments per level: row r = 4*jj + pat (cluster jj), k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2,
+    //      byte t&1) of the level; patterns LL / M / HH as in kmeans_pass_mfma_kernel
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const int jj = r >> 2, pat = r & 3;
+        const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
+        const unsigned sel = pat == 1 ? 0x02030001u : 0x03020100u;
+#pragma unroll
+        for (int L = 0; L < 4; ++L)
+#pragma unroll
+            for (int kk = 0; kk < NV_KS; ++kk) {
+                const v4i w = *reinterpret_cast<const v4i *>(&cs[(jj * 4 + L) * NV_DL + 16 * kk + 8 * h]);
+                v4i f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = (int)(__builtin_amdgcn_perm(0u, (unsigned)w[e], sel) & msk);
+                if (wave == 0) s_apat[L][kk][lane] = f;
+            }
+    }
+    __syncthreads();                                   // scratch reads done: the tile buffer is free
+    v4i accu[NL][NV_NT];
+#pragma unroll
+    for (int L = 0; L < NL; ++L)
+#pragma unroll
+        for (int nt = 0; nt < NV_NT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
+    int cntacc = 0;
+
+    // ---- staging: chunk ci (16 bytes at byte 16*ci of the tile) keeps its place inside its level; level-0 and level-1
+    //      plane rows get the bank padding of NV_P0 / NV_P1
+    const int nchunk = lo.tile_bytes >> 4;
+    const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
+              c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
+    v4i st[NV_NST];
+    int sdst[NV_NST];
+#pragma unroll
+    for (int i = 0; i < NV_NST; ++i) {
+        const int ci = min(tid + 256 * i, nchunk - 1);
+        int d;
+        if (ci < c1s) d = (ci >> 5) * NV_P0 + (ci & 31) * 16;
+        else if (ci < c2s) d = NV_OFF1 + ((ci - c1s) >> 3) * NV_P1 + ((ci - c1s) & 7) * 16;
+        else if (ci < c3s) d = NV_OFF2 + (ci - c2s) * 16;
+        else d = NV_OFF3 + (ci - c3s) * 16;
+        sdst[i] = (int)(size_t)&s_tile[d];
+    }
+    auto stage_load = [&](int tile) {
+        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
+#pragma unroll
+        for (int i = 0; i < NV_NST; ++i) st[i] = src[min(tid + 256 * i, nchunk - 1)];
+    };
+    typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = st[i];
+    };
+
+    const int un = lane & 15, ug = lane >> 4;             // update operand coordinates: cluster / byte-plane column, pixel group
+    const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
+    const unsigned eqr = (unsigned)un * 0x01010101u;
+
+    auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
+    int ltile = working ? g : nlist;
+    if (ltile < nlist) stage_load(phys(ltile));
+    const int s1 = __builtin_amdgcn_readfirstlane(G % ntiles);
+    const int q1 = __builtin_amdgcn_readfirstlane(4 * s1 / lo.bx_n), r1 = 4 * s1 - q1 * lo.bx_n;
+    const int q2 = __builtin_amdgcn_readfirstlane(4 * (ntiles - s1) / lo.bx_n), r2 = 4 * (ntiles - s1) - q2 * lo.bx_n;
+    int tin = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) % ntiles);
+    int by, bx;
+    {
+        const int blk0 = 4 * tin + wave;
+        by = blk0 / lo.bx_n;
+        bx = blk0 - by * lo.bx_n;
+    }
+    for (; ltile < nlist; ltile += G) {
+        const int tile = phys(ltile);
+        stage_write();
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(3);
+        if (ltile + G < nlist) stage_load(phys(ltile + G));   // in flight during the MFMAs
+        __builtin_amdgcn_s_setprio(0);
+
+        const int blk = 4 * tin + wave;
+        const int n = lane & 31, h = lane >> 5;
+        const int i16 = lane & 15, pxblk = (lane >> 4) & 1;
+        // -------- assign. All transpose reads of the tile go out first (coarse levels, then both level-0 sub-tiles), one wait.
+        // level 1: the block's 16 parents are columns 16*wave .. +15; level 2: its 4 parents are columns 4*wave .. +3 of
+        // the plane's 16; level 3: its parent is column `wave` of the plane's 4 (the transpose read wants 8-byte-aligned
+        // column starts, so these two read the whole plane row)
+        v2i ca[3][NV_KS], cb[3][NV_KS], fa0[2][NV_KS], fb0[2][NV_KS];
+        const int rowq = 8 * h + (i16 >> 2), colq = 16 * pxblk + 4 * (i16 & 3);
+        if (NL > 1) nv_issue<NV_P1>((unsigned)(size_t)&s_tile[NV_OFF1 + rowq * NV_P1 + (16 * wave + colq) * 2], ca[0], cb[0]);
+        if (NL > 2) nv_issue<NV_P2>((unsigned)(size_t)&s_tile[NV_OFF2 + rowq * NV_P2 + colq * 2], ca[1], cb[1]);
+        if (NL > 3) nv_issue<NV_P3>((unsigned)(size_t)&s_tile[NV_OFF3 + rowq * NV_P3 + colq * 2], ca[2], cb[2]);
+        nv_wait();
+        // coarse levels: (U, R2) per cluster and parent of this wave's block -> s_part[wave]
+#pragma unroll
+        for (int L = 1; L < NL; ++L) {
+            v4i bfr[NV_KS];
+            nv_take(ca[L - 1], cb[L - 1], bfr);
+            if (L == NL - 1)                                    // the level-0 reads travel while the last coarse chain runs
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    nv_issue<NV_P0>((unsigned)(size_t)&s_tile[rowq * NV_P0 + (wave * 64 + sub * 32 + colq) * 2], fa0[sub], fb0[sub]);
+            v16i acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0;
+#pragma unroll
+            for (int kk = 0; kk < NV_KS; ++kk)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_apat[L][kk][lane], bfr[kk], acc, 0, 0, 0);
+            const bool keep = L == 1 ? n < 16 : L == 2 ? (n >> 2) == wave : n == wave;
+            const int pidx = L == 1 ? (n & 15) : L == 2 ? (n & 3) : 0;
+            if (keep)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    s_part[wave][L - 1][2 * gq + h][pidx] = int2{__mul24(acc[4 * gq + 1], 256) + acc[4 * gq], acc[4 * gq + 2]};
+        }
+        // level 0: two 32-pixel sub-tiles (rows 4*sub .. 4*sub+3 of the block), both chains interleaved
+        v16i acc0[2];
+        {
+            v4i bfr[2][NV_KS];
+            nv_wait();
+            nv_take(fa0[0], fb0[0], bfr[0]);
+            nv_take(fa0[1], fb0[1], bfr[1]);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc0[sub][e] = 0;
+#pragma unroll
+            for (int kk = 0; kk < NV_KS; ++kk) {
+                const v4i a0 = s_apat[0][kk][lane];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    acc0[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bfr[sub][kk], acc0[sub], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int pl = wave * 64 + sub * 32 + n;
+            const int yi = 4 * sub + (n >> 3), xi = n & 7;      // pixel inside the block
+            const int p1 = (yi >> 1) * 4 + (xi >> 1), p2 = (yi >> 2) * 2 + (xi >> 2);
+            int2 cp[3][4];                                       // the coarse parts of this pixel's four clusters: loads first
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (NL > 1) cp[0][gq] = s_part[wave][0][2 * gq + h][p1];
+                if (NL > 2) cp[1][gq] = s_part[wave][1][2 * gq + h][p2];
+                if (NL > 3) cp[2][gq] = s_part[wave][2][2 * gq + h][0];
+            }
+            long long best = 0x7fffffffffffffffLL;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int j = 2 * gq + h;
+                int u = __mul24(acc0[sub][4 * gq + 1], 256) + acc0[sub][4 * gq], r2v = acc0[sub][4 * gq + 2];
+#pragma unroll
+                for (int L = 1; L < NL; ++L) {
+                    u += cp[L - 1][gq].x;
+                    r2v += cp[L - 1][gq].y;
+                }
+                long long key = mad_i64_i32(u, -32, s_const[j]);
+                key = mad_i64_i32(r2v, -2097152, key);
+                best = key < best ? key : best;
+            }
+            const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
+            const auto s1v = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
+            const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1v[0] : s1v[1];
+            const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
+            const int bj = (int)((pb < best ? pb : best) & 15);
+            if (h == 0) {
+                const int y = 8 * by + yi, x = 8 * bx + xi;
+                const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
+                s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
+                if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
+            }
+        }
+        // -------- update (the block's labels were written by this wave: no barrier). Operand loads of a level go out together.
+        if (do_acc) {
+            const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
+            const int dq = un >> 1;                             // plane inside a tile of 8
+            v2i w1[NV_NT];
+            unsigned w2[NV_NT], w3[NV_NT];
+            if (NL > 1)
+#pragma unroll
+                for (int nt = 0; nt < NV_NT; ++nt)
+                    w1[nt] = *reinterpret_cast<const v2i *>(&s_tile[NV_OFF1 + (8 * nt + dq) * NV_P1 + (wave * 16 + 4 * ug) * 2]);
+            v4i oh;                                              // byte 0x80 where label == un (pixels 16*ug .. +15 = rows 2ug, 2ug+1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned x = (unsigned)lw[i] ^ eqr;
+                const unsigned y = (x | 0x80808080u) - 0x01010101u;
+                oh[i] = (int)(~y & 0x80808080u);
+            }
+            cntacc += __builtin_popcount((unsigned)oh[0]) + __builtin_popcount((unsigned)oh[1]) +
+                      __builtin_popcount((unsigned)oh[2]) + __builtin_popcount((unsigned)oh[3]);
+            // level 0: one-hot digit -128 over the 64 pixels, three plane tiles at a time
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                v4i w0a[3], w0b[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const v4i *src = reinterpret_cast<const v4i *>(&s_tile[(8 * (3 * half + q) + dq) * NV_P0 + (wave * 64 + 16 * ug) * 2]);
+                    w0a[q] = src[0];
+                    w0b[q] = src[1];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    v4i bq;
+                    bq[0] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][1], (unsigned)w0a[q][0], usel);
+                    bq[1] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][3], (unsigned)w0a[q][2], usel);
+                    bq[2] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][1], (unsigned)w0b[q][0], usel);
+                    bq[3] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][3], (unsigned)w0b[q][2], usel);
+                    accu[0][3 * half + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq, accu[0][3 * half + q], 0, 0, 0);
+                }
+            }
+            if (NL > 2)
+#pragma unroll
+                for (int nt = 0; nt < NV_NT; ++nt)
+                    w2[nt] = *reinterpret_cast<const unsigned *>(&s_tile[NV_OFF2 + (8 * nt + dq) * NV_P2 + (wave * 4 + (ug >> 1) * 2) * 2]);
+            if (NL > 3)
+#pragma unroll
+                for (int nt = 0; nt < NV_NT; ++nt)
+                    w3[nt] = *reinterpret_cast<const uint16_t *>(&s_tile[NV_OFF3 + (8 * nt + dq) * NV_P3 + wave * 2]);
+            if (NL > 1) {
+                // counts of label un under the 4 level-1 parents of pixel rows 2ug, 2ug+1 (parent row ug, columns 0..3)
+                const unsigned e0 = (unsigned)oh[0] >> 7, e1 = (unsigned)oh[1] >> 7, e2 = (unsigned)oh[2] >> 7, e3 = (unsigned)oh[3] >> 7;
+                const unsigned sa = e0 + e2, sb = e1 + e3;       // bytes: columns 0..3 / 4..7, both rows
+                const unsigned ta = (sa & 0x00ff00ffu) + ((sa >> 8) & 0x00ff00ffu);   // parents 0 | 1 << 16
+                const unsigned tb = (sb & 0x00ff00ffu) + ((sb >> 8) & 0x00ff00ffu);   // parents 2 | 3 << 16
+                const unsigned c4 = __builtin_amdgcn_perm(tb, ta, 0x06040200u);       // bytes: parents 0, 1, 2, 3
+                const v4i a1 = v4i{(int)c4, 0, 0, 0};
+#pragma unroll
+                for (int nt = 0; nt < NV_NT; ++nt) {
+                    const v4i bq = v4i{(int)__builtin_amdgcn_perm((unsigned)w1[nt][1], (unsigned)w1[nt][0], usel), 0, 0, 0};
+                    accu[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bq, accu[1][nt], 0, 0, 0);
+                }
+                if (NL > 2) {
+                    // level 2: k-slots (ug, left / right half): partial counts of the parent (ug >> 1, half)
+                    const unsigned cl = (ta & 0xffu) + (ta >> 16), cr = (tb & 0xffu) + (tb >> 16);
+                    const v4i a2 = v4i{(int)(cl | (cr << 8)), 0, 0, 0};
+#pragma unroll
+                    for (int nt = 0; nt < NV_NT; ++nt) {
+                        const v4i bq = v4i{(int)__builtin_amdgcn_perm(w2[nt], w2[nt], usel), 0, 0, 0};
+                        accu[2][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, bq, accu[2][nt], 0, 0, 0);
+                    }
+                    if (NL > 3) {
+                        const v4i a3 = v4i{(int)(cl + cr), 0, 0, 0};     // level 3: k-slot ug, the block's one parent
+#pragma unroll
+                        for (int nt = 0; nt < NV_NT; ++nt) {
+                            const v4i bq = v4i{(int)((un & 1) ? (w3[nt] >> 8) : (w3[nt] & 255u)), 0, 0, 0};
+                            accu[3][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, bq, accu[3][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        {                                                        // next tile of this workgroup (see kmeans_pass_mfma_kernel)
+            const int tn = reverse ? tin - s1 : tin + s1;
+            const bool wrap = reverse ? tn < 0 : tn >= ntiles;
+            const bool up = reverse == wrap;
+            const int dq = wrap ? q2 : q1, dr = wrap ? r2 : r1;
+            tin = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
+            if (up) {
+                bx += dr;
+                by += dq;
+                if (bx >= lo.bx_n) { bx -= lo.bx_n; ++by; }
+            } else {
+                bx -= dr;
+                by -= dq;
+                if (bx < 0) { bx += lo.bx_n; --by; }
+            }
+        }
+        __syncthreads();
+    }
+    if (!do_acc) return;
+
+    // ---- fold: voting pixel counts first, then one level at a time through the tile buffer ([4 waves][16][96] ints)
+    s_cnt[wave][ug][un] = cntacc;
+    __syncthreads();
+    if (tid < 16) {
+        long long c = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int q = 0; q < 4; ++q) c += s_cnt[w][q][tid];
+        s_nj[tid] = c;
+    }
+    auto prow = [&](int i) -> size_t {                           // partial_index() of common.h for this kernel's (B, parts) grid
+        return per_image ? ((size_t)b * (K * D1) + i) * parts + part : (size_t)i * ((size_t)nb * parts) + (size_t)b * parts + part;
+    };
+    constexpr int RW = NV_NT * 16;
+    int *red = reinterpret_cast<int *>(s_tile);
+    static_assert(4 * 16 * RW * 4 <= NV_TILE, "fold buffer exceeds the tile buffer");
+#pragma unroll
+    for (int L = 0; L < NL; ++L) {
+        __syncthreads();                                          // previous level's reads (and s_nj) done
+#pragma unroll
+        for (int nt = 0; nt < NV_NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[L][nt][e];
+        __syncthreads();
+        const int DLv = lo.DL[L];
+        for (int i = tid; i < K * DLv; i += 256) {
+            const int j = i / DLv, pl = i % DLv;
+            long long flo = 0, fhi = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                flo += red[(w * 16 + j) * RW + 2 * pl];
+                fhi += red[(w * 16 + j) * RW + 2 * pl + 1];
+            }
+            if (L == 0) {                                         // the one-hot digit is -128
+                flo = -flo / 128;
+                fhi = -fhi / 128;
+            }
+            const long long nj = s_nj[j];
+            const long long out = (flo + 128 * nj) + 256 * (fhi + 128 * nj);
+            const int e = gcs_logical_of_plane(lo, lo.row0[L] + pl);
+            partials[prow(j * D1 + e)] = (uint64_t)out;
+        }
+    }
+    if (tid < K) partials[prow(tid * D1 + D)] = (uint64_t)s_nj[tid];
+}
+
 static size_t assign_lds_bytes(int D, int k, int R) {
     size_t a = ((size_t)D * k * 2 * 4 + 15) & ~(size_t)15;
     size_t c = ((size_t)k * 8 + 15) & ~(size_t)15;
@@ -687,8 +1105,25 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
                 else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
             }
         } else if (k <= 8) {
+            bool native = nchunk <= 256 * NV_NST && lo.n_levels >= 2;     // every level at most 48 planes: levels at own resolution
+            for (int L = 0; L < lo.n_levels; ++L) native = native && lo.DL[L] <= NV_DL;
+#ifdef GCS_KP_NO_NATIVE
+            native = false;
+#endif
+            if (native) {
+                // two 4-wave workgroups per CU are resident: 512 of the workgroups work, the others write zero partial rows
+                const int parts_eff = parts < 512 / B ? parts : (512 / B > 0 ? 512 / B : 1);
+#define GCS_NV_LAUNCH(NL_)                                                                                                \
+    hipLaunchKernelGGL(kmeans_pass_native_kernel<NL_>, dim3(B, parts), dim3(256), 0, stream,                              \
+                       reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
+                       reverse ? 1 : 0, row_lo, row_hi, labels, partials)
+                if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
+                else if (lo.n_levels == 3) GCS_NV_LAUNCH(3);
+                else GCS_NV_LAUNCH(4);
+#undef GCS_NV_LAUNCH
+            }
             // pyramid banks (config 4: 2 040 chunks per tile) fit 5 chunks per thread of an 8-wave workgroup without spills
-            if ((nchunk + 511) / 512 <= 5) { GCS_KP_LAUNCHW(1, 5, KP_DSTEPS_WIDE, 8); }
+            else if ((nchunk + 511) / 512 <= 5) { GCS_KP_LAUNCHW(1, 5, KP_DSTEPS_WIDE, 8); }
             else if (nst <= 18) { GCS_KP_LAUNCH(1, 18, KP_DSTEPS_WIDE); }
             else { GCS_KP_LAUNCH(1, 26, KP_DSTEPS_WIDE); }
         } else {
