@@ -693,6 +693,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
     const size_t img0 = per_image ? (size_t)b * ntiles : 0;
     const unsigned char *fb = feats + img0 * lo.tile_bytes;
     uint8_t *lb = labels + img0 * KP_TP;
+    auto prow = [&](int i) -> size_t {                           // partial_index() of common.h for this kernel's (B, parts) grid
+        return per_image ? ((size_t)b * (K * D1) + i) * parts + part : (size_t)i * ((size_t)nb * parts) + (size_t)b * parts + part;
+    };
+    if (!working) {                                              // a zero partial row, nothing else
+        if (do_acc)
+            for (int i = tid; i < K * D1; i += 256) partials[prow(i)] = 0;
+        return;
+    }
 
     // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
     const unsigned eqr = (unsigned)un * 0x01010101u;
 
     auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
-    int ltile = working ? g : nlist;
+    int ltile = g;
     if (ltile < nlist) stage_load(phys(ltile));
     const int s1 = __builtin_amdgcn_readfirstlane(G % ntiles);
     const int q1 = __builtin_amdgcn_readfirstlane(4 * s1 / lo.bx_n), r1 = 4 * s1 - q1 * lo.bx_n;
@@ -1008,9 +1016,6 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
             for (int q = 0; q < 4; ++q) c += s_cnt[w][q][tid];
         s_nj[tid] = c;
     }
-    auto prow = [&](int i) -> size_t {                           // partial_index() of common.h for this kernel's (B, parts) grid
-        return per_image ? ((size_t)b * (K * D1) + i) * parts + part : (size_t)i * ((size_t)nb * parts) + (size_t)b * parts + part;
-    };
     constexpr int RW = NV_NT * 16;
     int *red = reinterpret_cast<int *>(s_tile);
     static_assert(4 * 16 * RW * 4 <= NV_TILE, "fold buffer exceeds the tile buffer");
