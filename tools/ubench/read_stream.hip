@@ -190,6 +190,10 @@ int main() {
         time2([&] { stream_e<1440, 4><<<dim3(16, 64), 256>>>(src, tpi, 16, out); }, "E: 23 KB tiles, 4 WG/CU, 64 x parts=16");
         time2([&] { stream_e<1440, 6><<<dim3(24, 64), 256>>>(src, tpi, 24, out); }, "E: 23 KB tiles, 6 WG/CU, 64 x parts=24");
         time2([&] { stream_e<1440, 2><<<dim3(8, 64), 256>>>(src, tpi, 8, out); }, "E: 23 KB tiles, 2 WG/CU, 64 x parts=8");
+        // the batch as ONE tile list (what the global-codebook pass does since round 2): all workgroups interleaved
+        time2([&] { stream_e<1440, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 23 KB tiles, 3 WG/CU, one list of 768");
+        time2([&] { stream_e<1440, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 23 KB tiles, 4 WG/CU, one list of 1024");
+        time2([&] { stream_e<1440, 2><<<dim3(512, 1), 256>>>(src, 64 * tpi, 512, out); }, "E: 23 KB tiles, 2 WG/CU, one list of 512");
     }
     return 0;
 }
