@@ -69,7 +69,7 @@ extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
 }
 extern "C" size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k) {
     if (B <= 0 || D <= 0 || k <= 0) return 0;
-    return (size_t)B * gcs_kmeans_parts_per_image(B, H, W) * k * (D + 1) * sizeof(uint64_t);
+    return (size_t)B * gcs_kmeans_parts_per_image(B, H, W) * partial_chunks(k * (D + 1)) * KP_PCH * sizeof(uint64_t);
 }
 
 // ------------------------------------------------------------------------ bank pack (host)

@@ -118,10 +118,16 @@ __device__ __forceinline__ size_t gcs_slab_offset(const GcsLayout &lo, int b, in
            ((size_t)(r - lo.row0[L]) * npl + (blk & 3) * side * side + iy * side + ix) * 2;
 }
 
-// Partial sums, element-major: [set][element i of k*(D+1)][rows of that set] uint64, rows = the workgroups that
-// contribute to the set (per-image codebooks: the image's `parts`; one codebook: all gridDim.y * parts). The
-// values an output element is summed from are then one contiguous run for kmeans_reduce_kernel.
-__device__ __forceinline__ size_t partial_index(int per_image, int b, int part, int parts, int i, int row_len) {
-    return per_image ? ((size_t)b * row_len + i) * parts + part
-                     : (size_t)i * ((size_t)gridDim.y * parts) + (size_t)b * parts + part;
+// Partial sums of one Lloyd pass: [set][chunk of 16 elements][row][16] uint64, one row per k-means workgroup (sets = images
+// for per-image codebooks with `parts` rows each, one set of nb * parts rows otherwise). A workgroup writes whole 128-byte
+// lines (16 consecutive elements of ITS row: no line is shared between workgroups - with the element-major layout of
+// round 1 every 8-byte store was a partial-line write and the stores of a pass cost 4 us); the reduce kernel reads a
+// chunk's rows as one contiguous block. The padding elements of the last chunk are never written and never used.
+constexpr int KP_PCH = 16;
+__host__ __device__ __forceinline__ int partial_chunks(int row_len) { return (row_len + KP_PCH - 1) / KP_PCH; }
+__device__ __forceinline__ size_t partial_index(int per_image, int b, int part, int parts, int nb, int i, int row_len) {
+    const size_t rows = per_image ? (size_t)parts : (size_t)nb * parts;
+    const size_t row = per_image ? (size_t)part : (size_t)b * parts + part;
+    const size_t set = per_image ? (size_t)b : 0;
+    return ((set * partial_chunks(row_len) + (size_t)(i / KP_PCH)) * rows + row) * KP_PCH + (size_t)(i % KP_PCH);
 }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
         const int pe = e < D ? gcs_plane_of_logical(lo, e) : D;
         uint64_t s = 0;
         for (int rr = 0; rr < R; ++rr) s += acc[((size_t)j * D1 + pe) * R + rr];
-        partials[partial_index(per_image, b, part, parts, i, K * D1)] = s;
+        partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = s;
     }
 }
 
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const int pe = gcs_plane_of_logical(lo, e);
             out = (folded(j, 2 * pe) + 128 * nj) + 256 * (folded(j, 2 * pe + 1) + 128 * nj);
         }
-        partials[partial_index(per_image, b, part, parts, i, K * D1)] = (uint64_t)out;
+        partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = (uint64_t)out;
     }
 }
 
@@ -693,9 +693,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
     const size_t img0 = per_image ? (size_t)b * ntiles : 0;
     const unsigned char *fb = feats + img0 * lo.tile_bytes;
     uint8_t *lb = labels + img0 * KP_TP;
-    auto prow = [&](int i) -> size_t {                           // partial_index() of common.h for this kernel's (B, parts) grid
-        return per_image ? ((size_t)b * (K * D1) + i) * parts + part : (size_t)i * ((size_t)nb * parts) + (size_t)b * parts + part;
-    };
+    auto prow = [&](int i) -> size_t { return partial_index(per_image, b, part, parts, nb, i, K * D1); };
     if (!working) {                                              // a zero partial row, nothing else
         if (do_acc)
             for (int i = tid; i < K * D1; i += 256) partials[prow(i)] = 0;
@@ -1152,32 +1150,51 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
     return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
 }
 
-// sums[set][e] = sum of the set's partial values of element e (one contiguous run, see partial_index). Integer
-// sums: any order gives the same bits. One wave per element: coalesced reads, shuffle fold.
-// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in between): the wave
-// also folds the count element of its cluster, so no second kernel and no cross-block dependency is needed.
+// sums[set][e] = sum over the set's rows of element e (layout: partial_index in common.h). Integer sums: any order gives
+// the same bits. One 1024-thread workgroup per chunk of 16 elements: thread (row group rg = t >> 4, element t & 15) adds
+// rows rg, rg + 64, ...; a wave reads four whole rows = 512 contiguous bytes per load.
+// FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in between): every thread
+// also folds the count element of its element's cluster, so no second kernel and no cross-block dependency is needed.
 template <bool FIN>
-__global__ __launch_bounds__(256) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
-                                                            int rows_per_set, int row_len, int D1,
-                                                            long long *__restrict__ sums,
-                                                            uint16_t *__restrict__ cent) {
-    const int set = blockIdx.y, lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= row_len) return;                                  // whole waves leave; no barrier below
-    const int j = e / D1, d = e - j * D1;
-    const uint64_t *p = partials + ((size_t)set * row_len + e) * rows_per_set;
-    const uint64_t *pc = partials + ((size_t)set * row_len + j * D1 + (D1 - 1)) * rows_per_set;
+__global__ __launch_bounds__(1024) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
+                                                             int rows_per_set, int row_len, int D1,
+                                                             long long *__restrict__ sums,
+                                                             uint16_t *__restrict__ cent) {
+    __shared__ unsigned long long sm_s[64][KP_PCH], sm_c[64][KP_PCH];
+    const int set = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    const int e16 = t & (KP_PCH - 1), rg = t >> 4;
+    const int nch = partial_chunks(row_len);
+    const int e = chunk * KP_PCH + e16;
+    const int ee = e < row_len ? e : row_len - 1;              // padding columns of the last chunk: read a valid one
+    const int j = ee / D1, d = ee - j * D1;
+    const int ec = j * D1 + (D1 - 1);                          // the count element of this element's cluster
+    const uint64_t *p = partials + (((size_t)set * nch + chunk) * rows_per_set) * KP_PCH + (ee - chunk * KP_PCH);
+    const uint64_t *pc = partials + (((size_t)set * nch + ec / KP_PCH) * rows_per_set) * KP_PCH + ec % KP_PCH;
     uint64_t s = 0, c = 0;
-    for (int r = lane; r < rows_per_set; r += 64) {
-        s += p[r];
-        if (FIN) c += pc[r];
+    for (int r = rg; r < rows_per_set; r += 64) {
+        s += p[(size_t)r * KP_PCH];
+        if (FIN) c += pc[(size_t)r * KP_PCH];
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        s += __shfl_xor(s, m);
-        if (FIN) c += __shfl_xor(c, m);
+    sm_s[rg][e16] = s;
+    if (FIN) sm_c[rg][e16] = c;
+    __syncthreads();
+    if (t < 256) {                                             // 16 row groups of 4
+        s = sm_s[4 * rg][e16] + sm_s[4 * rg + 1][e16] + sm_s[4 * rg + 2][e16] + sm_s[4 * rg + 3][e16];
+        if (FIN) c = sm_c[4 * rg][e16] + sm_c[4 * rg + 1][e16] + sm_c[4 * rg + 2][e16] + sm_c[4 * rg + 3][e16];
     }
-    if (lane == 0) {
+    __syncthreads();
+    if (t < 256) {
+        sm_s[rg][e16] = s;
+        if (FIN) sm_c[rg][e16] = c;
+    }
+    __syncthreads();
+    if (t < KP_PCH && e < row_len) {
+        s = 0;
+        c = 0;
+        for (int q = 0; q < 16; ++q) {
+            s += sm_s[q][e16];
+            if (FIN) c += sm_c[q][e16];
+        }
         if (sums) sums[(size_t)set * row_len + e] = (long long)s;
         if (FIN && d < D1 - 1 && c > 0)
             cent[((size_t)set * (row_len / D1) + j) * (D1 - 1) + d] = (uint16_t)((2 * s + c) / (2 * c));
@@ -1198,7 +1215,7 @@ extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, 
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
+    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream, partials,
                        rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
     return GCS_OK;
@@ -1211,7 +1228,7 @@ extern "C" int gcs_kmeans_reduce_finalize(const uint64_t *partials, int B, int H
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3((row_len + 3) / 4, n_sets), dim3(256), 0, stream, partials,
+    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream, partials,
                        rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce_finalize");
     return GCS_OK;

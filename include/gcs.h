@@ -63,8 +63,8 @@ int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ksize, in
  * [B][D][H][W] uint16 tensor of SPEC.md §3. Label slab: uint8 in the same pixel order. */
 size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient);
 size_t gcs_label_slab_bytes(int B, int H, int W);
-/* uint64 partial sums written by one assign pass: B * parts * k * (D+1) values, one per k-means workgroup and
- * output element (element-major; opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */
+/* uint64 partial sums written by one assign pass: one row of k * (D+1) values per k-means workgroup, stored in chunks
+ * of 16 elements, padded (opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */
 size_t gcs_kmeans_parts_per_image(int B, int H, int W);
 size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
 

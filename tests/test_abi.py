@@ -49,7 +49,7 @@ def test_geometry(lib):
     assert lib.gcs_kmeans_parts_per_image(1, 321, 481) * 8 <= tiles                      # >= 8 tiles per workgroup
     assert lib.gcs_kmeans_parts_per_image(1, 2048, 2048) * 65536 >= 2048 * 2048
     assert lib.gcs_kmeans_parts_per_image(4096, 321, 481) * 65536 >= tiles * 256
-    assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * 8 * 73 * 8
+    assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * (-(-8 * 73 // 16) * 16) * 8   # chunks of 16 elements
     assert lib.gcs_feature_slab_bytes(0, 1, 1, 1, 1) == 0
     assert lib.gcs_gabor_workspace_bytes(1, 321, 481, 4) > 3 * (321 + 14) * (481 + 14) + 3 * (161 + 14) * (241 + 14)
     assert lib.gcs_gabor_workspace_bytes(1, 321, 481, 9) == 0

@@ -139,6 +139,7 @@ def test_lloyd_pass_with_one_output_only(torch_cuda, ns, no):
     seg.ops.gabor_features(imgs, ws["feats"])
     seg.ops.kmeans_init(ws["feats"], b, h, w, seg.k, 1, ws["cent"])
     lab2, par2 = torch.full_like(ws["labels"], 255), torch.zeros_like(ws["partials"])
+    ws["partials"].zero_()                                   # the padding of the chunked partial layout is never written
     seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, ws["labels"], ws["partials"])
     seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, lab2, None)
     seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, seg.k, 1, None, par2)
