@@ -1171,10 +1171,27 @@ __global__ __launch_bounds__(1024) void kmeans_reduce_kernel(const uint64_t *__r
     const uint64_t *p = partials + (((size_t)set * nch + chunk) * rows_per_set) * KP_PCH + (ee - chunk * KP_PCH);
     const uint64_t *pc = partials + (((size_t)set * nch + ec / KP_PCH) * rows_per_set) * KP_PCH + ec % KP_PCH;
     uint64_t s = 0, c = 0;
-    for (int r = rg; r < rows_per_set; r += 64) {
-        s += p[(size_t)r * KP_PCH];
-        if (FIN) c += pc[(size_t)r * KP_PCH];
-    }
+    int r = rg;
+    // the loop is latency-bound: 12 (then 4) rows in flight per thread
+    auto burst = [&](auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        for (; r + 64 * (N - 1) < rows_per_set; r += 64 * N) {
+            uint64_t a[N], q[N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                a[u] = p[(size_t)(r + 64 * u) * KP_PCH];
+                q[u] = FIN ? pc[(size_t)(r + 64 * u) * KP_PCH] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                s += a[u];
+                c += q[u];
+            }
+        }
+    };
+    burst(std::integral_constant<int, 12>{});
+    burst(std::integral_constant<int, 4>{});
+    burst(std::integral_constant<int, 1>{});
     sm_s[rg][e16] = s;
     if (FIN) sm_c[rg][e16] = c;
     __syncthreads();
