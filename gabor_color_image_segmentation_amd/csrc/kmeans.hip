@@ -1287,9 +1287,18 @@ __global__ __launch_bounds__(256) void labels_raster_kernel(const uint8_t *__res
         const int blk = (y >> 3) * bx_n + (x4 >> 1);
         const unsigned v = *reinterpret_cast<const unsigned *>(img + (size_t)(blk >> 2) * KP_TP + (blk & 3) * 64 +
                                                                (y & 7) * 8 + (x4 & 1) * 4);
+        if (sizeof(OUT) == 4 && 4 * x4 + 3 < W) {        // one 16-byte store (any 4-byte alignment: rows of W ints start anywhere)
+            typedef int __attribute__((ext_vector_type(4), aligned(4))) v4i_a4;
+            *reinterpret_cast<v4i_a4 *>(dst + 4 * x4) =
+                v4i_a4{(int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24)};
+        } else if (sizeof(OUT) == 1 && 4 * x4 + 3 < W) {
+            typedef unsigned __attribute__((aligned(1))) u32_a1;
+            *reinterpret_cast<u32_a1 *>(dst + 4 * x4) = v;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * x4 + e < W) dst[4 * x4 + e] = (OUT)((v >> (8 * e)) & 255u);
+            for (int e = 0; e < 4; ++e)
+                if (4 * x4 + e < W) dst[4 * x4 + e] = (OUT)((v >> (8 * e)) & 255u);
+        }
     }
 }
 
