@@ -639,12 +639,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 //            voting pixels of label j under a parent (level 0: the one-hot digit -128 as in the other pass; coarse
 //            levels: small positive counts built from the one-hot bytes); n_j by v_bcnt.
 // Same tile list, sweep order, validity rules, outputs and partial layout as kmeans_pass_mfma_kernel.
-constexpr int NV_DL = 48, NV_KS = 3, NV_NT = 6;              // planes, assign K-steps, update plane tiles per level
+constexpr int NV_DL = 48, NV_KS = 3;                         // planes (LDS rows) and assign K-steps per level
 constexpr int NV_P0 = KP_TP * 2 + 64, NV_P1 = 128 + 32, NV_P2 = 32, NV_P3 = 8;   // LDS bytes per plane row of level L
 constexpr int NV_OFF1 = NV_DL * NV_P0, NV_OFF2 = NV_OFF1 + NV_DL * NV_P1, NV_OFF3 = NV_OFF2 + NV_DL * NV_P2;
 constexpr int NV_END = NV_OFF3 + NV_DL * NV_P3;
-constexpr int NV_TILE = NV_END + 512;                        // room for the over-reads of unused MFMA columns / planes
-constexpr int NV_NST = 8;                                    // 16-byte staging chunks per thread (tile <= 32 640 B)
 
 // B fragments by hardware transpose (see kmeans_pass_mfma_kernel): issue only; nv_wait() then waits once for everything
 template <int PITCH>
@@ -666,16 +664,18 @@ __device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i 
     }
 }
 
-template <int NL>
-__global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
+// NT = update plane tiles per level (8 planes each), NST = 16-byte staging chunks per thread, MINB = workgroups per CU
+template <int NL, int NT, int NST, int MINB>
+__global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels,
     uint64_t *__restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_tile[NV_TILE];
-    __shared__ __attribute__((aligned(16))) int2 s_part[4][3][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
+    constexpr int TILE_B = (NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END) + 512;   // + room for the over-reads of unused columns
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[TILE_B];
+    __shared__ __attribute__((aligned(16))) int2 s_part[4][NL - 1][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
-    __shared__ __attribute__((aligned(16))) v4i s_apat[4][NV_KS][64];   // assign A fragments per level (lane-linear; used once per tile)
+    __shared__ __attribute__((aligned(16))) v4i s_apat[NL][NV_KS][64];  // assign A fragments per level (lane-linear; used once per tile)
     __shared__ int s_cnt[4][4][16];                                     // [wave][pixel group][cluster] voting pixels
     __shared__ long long s_nj[16];
 
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
         const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
         const unsigned sel = pat == 1 ? 0x02030001u : 0x03020100u;
 #pragma unroll
-        for (int L = 0; L < 4; ++L)
+        for (int L = 0; L < NL; ++L)
 #pragma unroll
             for (int kk = 0; kk < NV_KS; ++kk) {
                 const v4i w = *reinterpret_cast<const v4i *>(&cs[(jj * 4 + L) * NV_DL + 16 * kk + 8 * h]);
@@ -752,11 +752,11 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
             }
     }
     __syncthreads();                                   // scratch reads done: the tile buffer is free
-    v4i accu[NL][NV_NT];
+    v4i accu[NL][NT];
 #pragma unroll
     for (int L = 0; L < NL; ++L)
 #pragma unroll
-        for (int nt = 0; nt < NV_NT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
+        for (int nt = 0; nt < NT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
     int cntacc = 0;
 
     // ---- staging: chunk ci (16 bytes at byte 16*ci of the tile) keeps its place inside its level; level-0 and level-1
@@ -764,10 +764,10 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
     const int nchunk = lo.tile_bytes >> 4;
     const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
               c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
-    v4i st[NV_NST];
-    int sdst[NV_NST];
+    v4i st[NST];
+    int sdst[NST];
 #pragma unroll
-    for (int i = 0; i < NV_NST; ++i) {
+    for (int i = 0; i < NST; ++i) {
         const int ci = min(tid + 256 * i, nchunk - 1);
         int d;
         if (ci < c1s) d = (ci >> 5) * NV_P0 + (ci & 31) * 16;
@@ -779,12 +779,12 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NV_NST; ++i) st[i] = src[min(tid + 256 * i, nchunk - 1)];
+        for (int i = 0; i < NST; ++i) st[i] = src[min(tid + 256 * i, nchunk - 1)];
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = st[i];
+        for (int i = 0; i < NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = st[i];
     };
 
     const int un = lane & 15, ug = lane >> 4;             // update operand coordinates: cluster / byte-plane column, pixel group
@@ -909,11 +909,11 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
         if (do_acc) {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
             const int dq = un >> 1;                             // plane inside a tile of 8
-            v2i w1[NV_NT];
-            unsigned w2[NV_NT], w3[NV_NT];
+            v2i w1[NT];
+            unsigned w2[NT], w3[NT];
             if (NL > 1)
 #pragma unroll
-                for (int nt = 0; nt < NV_NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     w1[nt] = *reinterpret_cast<const v2i *>(&s_tile[NV_OFF1 + (8 * nt + dq) * NV_P1 + (wave * 16 + 4 * ug) * 2]);
             v4i oh;                                              // byte 0x80 where label == un (pixels 16*ug .. +15 = rows 2ug, 2ug+1)
 #pragma unroll
@@ -926,31 +926,34 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
                       __builtin_popcount((unsigned)oh[2]) + __builtin_popcount((unsigned)oh[3]);
             // level 0: one-hot digit -128 over the 64 pixels, three plane tiles at a time
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                v4i w0a[3], w0b[3];
+            for (int base = 0; base < NT; base += 3) {
+                constexpr int GRP = 3;
+                v4i w0a[GRP], w0b[GRP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const v4i *src = reinterpret_cast<const v4i *>(&s_tile[(8 * (3 * half + q) + dq) * NV_P0 + (wave * 64 + 16 * ug) * 2]);
-                    w0a[q] = src[0];
-                    w0b[q] = src[1];
-                }
+                for (int q = 0; q < GRP; ++q)
+                    if (base + q < NT) {
+                        const v4i *src = reinterpret_cast<const v4i *>(&s_tile[(8 * (base + q) + dq) * NV_P0 + (wave * 64 + 16 * ug) * 2]);
+                        w0a[q] = src[0];
+                        w0b[q] = src[1];
+                    }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    v4i bq;
-                    bq[0] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][1], (unsigned)w0a[q][0], usel);
-                    bq[1] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][3], (unsigned)w0a[q][2], usel);
-                    bq[2] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][1], (unsigned)w0b[q][0], usel);
-                    bq[3] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][3], (unsigned)w0b[q][2], usel);
-                    accu[0][3 * half + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq, accu[0][3 * half + q], 0, 0, 0);
-                }
+                for (int q = 0; q < GRP; ++q)
+                    if (base + q < NT) {
+                        v4i bq;
+                        bq[0] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][1], (unsigned)w0a[q][0], usel);
+                        bq[1] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][3], (unsigned)w0a[q][2], usel);
+                        bq[2] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][1], (unsigned)w0b[q][0], usel);
+                        bq[3] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][3], (unsigned)w0b[q][2], usel);
+                        accu[0][base + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq, accu[0][base + q], 0, 0, 0);
+                    }
             }
             if (NL > 2)
 #pragma unroll
-                for (int nt = 0; nt < NV_NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     w2[nt] = *reinterpret_cast<const unsigned *>(&s_tile[NV_OFF2 + (8 * nt + dq) * NV_P2 + (wave * 4 + (ug >> 1) * 2) * 2]);
             if (NL > 3)
 #pragma unroll
-                for (int nt = 0; nt < NV_NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     w3[nt] = *reinterpret_cast<const uint16_t *>(&s_tile[NV_OFF3 + (8 * nt + dq) * NV_P3 + wave * 2]);
             if (NL > 1) {
                 // counts of label un under the 4 level-1 parents of pixel rows 2ug, 2ug+1 (parent row ug, columns 0..3)
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
                 const unsigned c4 = __builtin_amdgcn_perm(tb, ta, 0x06040200u);       // bytes: parents 0, 1, 2, 3
                 const v4i a1 = v4i{(int)c4, 0, 0, 0};
 #pragma unroll
-                for (int nt = 0; nt < NV_NT; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const v4i bq = v4i{(int)__builtin_amdgcn_perm((unsigned)w1[nt][1], (unsigned)w1[nt][0], usel), 0, 0, 0};
                     accu[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bq, accu[1][nt], 0, 0, 0);
                 }
@@ -970,14 +973,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
                     const unsigned cl = (ta & 0xffu) + (ta >> 16), cr = (tb & 0xffu) + (tb >> 16);
                     const v4i a2 = v4i{(int)(cl | (cr << 8)), 0, 0, 0};
 #pragma unroll
-                    for (int nt = 0; nt < NV_NT; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         const v4i bq = v4i{(int)__builtin_amdgcn_perm(w2[nt], w2[nt], usel), 0, 0, 0};
                         accu[2][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, bq, accu[2][nt], 0, 0, 0);
                     }
                     if (NL > 3) {
                         const v4i a3 = v4i{(int)(cl + cr), 0, 0, 0};     // level 3: k-slot ug, the block's one parent
 #pragma unroll
-                        for (int nt = 0; nt < NV_NT; ++nt) {
+                        for (int nt = 0; nt < NT; ++nt) {
                             const v4i bq = v4i{(int)((un & 1) ? (w3[nt] >> 8) : (w3[nt] & 255u)), 0, 0, 0};
                             accu[3][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, bq, accu[3][nt], 0, 0, 0);
                         }
@@ -1014,14 +1017,14 @@ __global__ __launch_bounds__(256, 2) void kmeans_pass_native_kernel(
             for (int q = 0; q < 4; ++q) c += s_cnt[w][q][tid];
         s_nj[tid] = c;
     }
-    constexpr int RW = NV_NT * 16;
+    constexpr int RW = NT * 16;
     int *red = reinterpret_cast<int *>(s_tile);
-    static_assert(4 * 16 * RW * 4 <= NV_TILE, "fold buffer exceeds the tile buffer");
+    static_assert(4 * 16 * RW * 4 <= TILE_B && 8 * 4 * NV_DL * 2 <= TILE_B, "fold / centroid scratch exceeds the tile buffer");
 #pragma unroll
     for (int L = 0; L < NL; ++L) {
         __syncthreads();                                          // previous level's reads (and s_nj) done
 #pragma unroll
-        for (int nt = 0; nt < NV_NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[L][nt][e];
         __syncthreads();
@@ -1108,7 +1111,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
                 else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
             }
         } else if (k <= 8) {
-            bool native = nchunk <= 256 * NV_NST && lo.n_levels >= 2;     // every level at most 48 planes: levels at own resolution
+            bool native = nchunk <= 256 * 8 && lo.n_levels >= 2;          // every level at most 48 planes: levels at own resolution
             for (int L = 0; L < lo.n_levels; ++L) native = native && lo.DL[L] <= NV_DL;
 #ifdef GCS_KP_NO_NATIVE
             native = false;
@@ -1117,7 +1120,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
                 // two 4-wave workgroups per CU are resident: 512 of the workgroups work, the others write zero partial rows
                 const int parts_eff = parts < 512 / B ? parts : (512 / B > 0 ? 512 / B : 1);
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
-    hipLaunchKernelGGL(kmeans_pass_native_kernel<NL_>, dim3(B, parts), dim3(256), 0, stream,                              \
+    hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
                        reverse ? 1 : 0, row_lo, row_hi, labels, partials)
                 if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
