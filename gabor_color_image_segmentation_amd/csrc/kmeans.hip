@@ -1158,12 +1158,14 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 // rows rg, rg + 64, ...; a wave reads four whole rows = 512 contiguous bytes per load.
 // FIN: the SPEC.md §4 update is applied in the same launch (single-rank case, no all-reduce in between): every thread
 // also folds the count element of its element's cluster, so no second kernel and no cross-block dependency is needed.
-template <bool FIN>
-__global__ __launch_bounds__(1024) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
+// RG = row groups per workgroup (threads = 16 * RG): 64 for the long row lists of one global codebook, 16 for the `parts`
+// rows of a per-image codebook.
+template <bool FIN, int RG>
+__global__ __launch_bounds__(16 * RG) void kmeans_reduce_kernel(const uint64_t *__restrict__ partials,
                                                              int rows_per_set, int row_len, int D1,
                                                              long long *__restrict__ sums,
                                                              uint16_t *__restrict__ cent) {
-    __shared__ unsigned long long sm_s[64][KP_PCH], sm_c[64][KP_PCH];
+    __shared__ unsigned long long sm_s[RG][KP_PCH], sm_c[RG][KP_PCH];
     const int set = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const int e16 = t & (KP_PCH - 1), rg = t >> 4;
     const int nch = partial_chunks(row_len);
@@ -1178,12 +1180,12 @@ __global__ __launch_bounds__(1024) void kmeans_reduce_kernel(const uint64_t *__r
     // the loop is latency-bound: 12 (then 4) rows in flight per thread
     auto burst = [&](auto n_c) {
         constexpr int N = decltype(n_c)::value;
-        for (; r + 64 * (N - 1) < rows_per_set; r += 64 * N) {
+        for (; r + RG * (N - 1) < rows_per_set; r += RG * N) {
             uint64_t a[N], q[N];
 #pragma unroll
             for (int u = 0; u < N; ++u) {
-                a[u] = p[(size_t)(r + 64 * u) * KP_PCH];
-                q[u] = FIN ? pc[(size_t)(r + 64 * u) * KP_PCH] : 0;
+                a[u] = p[(size_t)(r + RG * u) * KP_PCH];
+                q[u] = FIN ? pc[(size_t)(r + RG * u) * KP_PCH] : 0;
             }
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -1198,16 +1200,18 @@ __global__ __launch_bounds__(1024) void kmeans_reduce_kernel(const uint64_t *__r
     sm_s[rg][e16] = s;
     if (FIN) sm_c[rg][e16] = c;
     __syncthreads();
-    if (t < 256) {                                             // 16 row groups of 4
-        s = sm_s[4 * rg][e16] + sm_s[4 * rg + 1][e16] + sm_s[4 * rg + 2][e16] + sm_s[4 * rg + 3][e16];
-        if (FIN) c = sm_c[4 * rg][e16] + sm_c[4 * rg + 1][e16] + sm_c[4 * rg + 2][e16] + sm_c[4 * rg + 3][e16];
+    if (RG == 64) {                                            // 64 -> 16 row groups
+        if (t < 256) {
+            s = sm_s[4 * rg][e16] + sm_s[4 * rg + 1][e16] + sm_s[4 * rg + 2][e16] + sm_s[4 * rg + 3][e16];
+            if (FIN) c = sm_c[4 * rg][e16] + sm_c[4 * rg + 1][e16] + sm_c[4 * rg + 2][e16] + sm_c[4 * rg + 3][e16];
+        }
+        __syncthreads();
+        if (t < 256) {
+            sm_s[rg][e16] = s;
+            if (FIN) sm_c[rg][e16] = c;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (t < 256) {
-        sm_s[rg][e16] = s;
-        if (FIN) sm_c[rg][e16] = c;
-    }
-    __syncthreads();
     if (t < KP_PCH && e < row_len) {
         s = 0;
         c = 0;
@@ -1235,8 +1239,12 @@ extern "C" int gcs_kmeans_reduce(const uint64_t *partials, int B, int H, int W, 
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<false>, dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream, partials,
-                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
+    if (rows_per_set > 64)
+        hipLaunchKernelGGL((kmeans_reduce_kernel<false, 64>), dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream,
+                           partials, rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
+    else
+        hipLaunchKernelGGL((kmeans_reduce_kernel<false, 16>), dim3(partial_chunks(row_len), n_sets), dim3(256), 0, stream,
+                           partials, rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), (uint16_t *)nullptr);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce");
     return GCS_OK;
 }
@@ -1248,8 +1256,12 @@ extern "C" int gcs_kmeans_reduce_finalize(const uint64_t *partials, int B, int H
     const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
     const int row_len = k * (D + 1);
     const int rows_per_set = n_sets == B ? parts : B * parts;
-    hipLaunchKernelGGL(kmeans_reduce_kernel<true>, dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream, partials,
-                       rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
+    if (rows_per_set > 64)
+        hipLaunchKernelGGL((kmeans_reduce_kernel<true, 64>), dim3(partial_chunks(row_len), n_sets), dim3(1024), 0, stream,
+                           partials, rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
+    else
+        hipLaunchKernelGGL((kmeans_reduce_kernel<true, 16>), dim3(partial_chunks(row_len), n_sets), dim3(256), 0, stream,
+                           partials, rows_per_set, row_len, D + 1, reinterpret_cast<long long *>(sums), cent);
     GCS_CHECK_LAUNCH("gcs_kmeans_reduce_finalize");
     return GCS_OK;
 }
