@@ -190,3 +190,35 @@ def test_config4_full_size_vs_c_oracle(built):
     assert np.array_equal(got, co.gabor_features(imgs[0], tapq, shift, 8))
     lab = s.segment_batch(imgs, mode="global")
     assert np.array_equal(lab, co.segment_batch(imgs, tapq, shift, 8, n_iter=5, mode="global"))
+
+
+def test_bsd_val_boundary_f_gate(seg):
+    """The quality gate: 24 decoded BSD500 val images through the HIP path give the oracle's label
+    maps bit for bit, and the batched GPU scorer (gcs_boundary_counts_batch / gcs_region_counts_batch against the packed
+    ground truth of all 500 ids) gives exactly the P / R / F the reference's own metrics class
+    (/root/reference/BSD_metrics/metrics.py:58-96, run by tests/golden/make_bsd_val_scores.py) recorded for them."""
+    import torch
+    from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_batch_device
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
+    doc = json.load(open(os.path.join(GOLD, "bsd_val_scores.json")))
+    pack = np.load(os.path.join(GOLD, "bsd_val_images.npz"))
+    pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    ids = [str(i) for i in pack["ids"]]
+    f_gpu = []
+    for shape in ((321, 481), (481, 321)):
+        group = [i for i in ids if pack["img_" + i].shape[:2] == shape]
+        assert group
+        imgs = torch.from_numpy(np.stack([pack["img_" + i] for i in group])).cuda()
+        labs = seg.segment_device(imgs)                                  # per-image codebooks: script.py:22-30
+        host = labs.cpu().numpy()
+        for b, i in enumerate(group):
+            assert np.array_equal(host[b], pack["labels_" + i]), i
+        for i, g in zip(group, all_scores_batch_device(labs, *pt.stack(group))):
+            ref = doc["per_id"][i]["v2"]
+            assert g["regions"] == ref["regions"]
+            for key in ("recall", "precision", "fmeasure", "density"):
+                assert g[key] == ref[key], (i, key, g[key], ref[key])
+            for key in ("underseg", "undersegNP", "compactness"):
+                assert abs(g[key] - ref[key]) <= 1e-12, (i, key)
+            f_gpu.append(g["fmeasure"])
+    assert float(np.mean(f_gpu)) == float(np.mean([doc["per_id"][i]["v2"]["fmeasure"] for i in ids]))
