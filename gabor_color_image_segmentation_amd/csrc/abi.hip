@@ -36,7 +36,7 @@ extern "C" size_t gcs_bank_bias_count(int n_scales, int n_orient) {
     if (!bank_levels(n_scales, n_orient, FL, &nl)) return 0;
     size_t mt = 0;
     for (int L = 0; L < nl; ++L) mt += mtiles(FL[L]);
-    return mt * 8;
+    return mt * 4;
 }
 extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient) {
     GcsLayout lo;
@@ -77,9 +77,11 @@ extern "C" size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k) {
 // 32-row tile, 16 consecutive k. We bind k-slot (kk, h, j) to tap (dy = 2*kk + h, dx = j) of
 // a 16x16 frame whose row 15 / column 15 are zero; both operands use the same binding, so
 // only "A row = lane&31, B col = lane&31" and the C/D map (cdna guide §3) are relied on.
-// Row r of tile mt = filter 8*mt + r/4 OF ITS LEVEL, part r%4 in {re_lo, re_hi, im_lo, im_hi}: the four
-// parts of one filter land in one lane's accumulator quad (rows 4g..4g+3). Levels are packed one after
-// the other, each starting on a fresh tile: [level][mt][kk][lane][16 bytes]; bias [level][mt*8 + f%8].
+// Row r = 8i + 4hh + part of tile mt = filter 4*mt + 2*(i >> 1) + hh OF ITS LEVEL, part in {re_lo, re_hi, im_lo, im_hi},
+// evaluated for the pixel s = i & 1 to the right of the B column's pixel: its taps sit s slots further right in the frame
+// row (slot j holds dx = j - s; the frame is 16 wide, a 15-tap row shifted by one still fits). A lane's accumulator quads
+// (rows 8i + 4h .. +3, i = 0..3) are then the two pixels of a pair for the two filters 2fp + h of the tile. Levels are
+// packed one after the other, each starting on a fresh tile: [level][mt][kk][lane][16 bytes]; bias [level][mt*4 + f%4].
 extern "C" int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ks, int8_t *packed, int32_t *bias) {
     if (!tapq || !packed || !bias) return gcs_fail(GCS_EINVAL, "gcs_bank_pack: NULL pointer");
     int FL[GCS_LEVELS_MAX], nl;
@@ -95,26 +97,35 @@ extern "C" int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, in
         const int f0 = 2 * L * n_orient;
         for (int fl = 0; fl < FL[L]; ++fl) {
             const int f = f0 + fl;
-            long s_re = 0, s_im = 0;
+            long s_re = 0, s_im = 0, a_re = 0, a_im = 0;
             for (int t = 0; t < ks * ks; ++t) {
-                s_re += tapq[((size_t)f * 2 + 0) * ks * ks + t];
-                s_im += tapq[((size_t)f * 2 + 1) * ks * ks + t];
+                const int q_re = tapq[((size_t)f * 2 + 0) * ks * ks + t], q_im = tapq[((size_t)f * 2 + 1) * ks * ks + t];
+                s_re += q_re;
+                s_im += q_im;
+                a_re += q_re < 0 ? -q_re : q_re;
+                a_im += q_im < 0 ? -q_im : q_im;
             }
             if (s_im != 0) return gcs_fail(GCS_EINVAL, "gcs_bank_pack: imaginary taps must sum to zero");
-            bias[mt_base * 8 + fl] = (int32_t)(128 * s_re);
+            // |response| <= 255 * sum|tapq| must stay below 2^23, so that the Q7 value (response >> 8 at the Q15 shift) is a
+            // 16-bit integer and re^2 + im^2 < 2^31: the domain of the kernel's exact square root (SPEC.md §3; an envelope of
+            // unit DC gain gives sum|tapq| <= 2^15 + ks^2 / 2)
+            if (a_re > GCS_TAP_ABS_SUM_MAX || a_im > GCS_TAP_ABS_SUM_MAX)
+                return gcs_fail(GCS_EINVAL, "gcs_bank_pack: sum of |tapq| of a filter exceeds 32896 (response would leave 24 bits)");
+            bias[mt_base * 4 + fl] = (int32_t)(128 * s_re);
         }
         for (int mt = 0; mt < mtiles(FL[L]); ++mt)
             for (int kk = 0; kk < 8; ++kk)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 31, h = lane >> 5;
-                    const int fl = 8 * mt + r / 4, part = r & 3;
+                    const int i = r >> 3, hh = (r >> 2) & 1, part = r & 3;
+                    const int fl = 4 * mt + 2 * (i >> 1) + hh, s = i & 1;
                     int8_t *dst = packed + (((size_t)(mt_base + mt) * 8 + kk) * 64 + lane) * 16;
                     if (fl >= FL[L]) continue;
                     const int f = f0 + fl;
                     const int dy = 2 * kk + h - off;
                     if (dy < 0 || dy >= ks) continue;
                     for (int j = 0; j < 16; ++j) {
-                        const int dx = j - off;
+                        const int dx = j - s - off;
                         if (dx < 0 || dx >= ks) continue;
                         const int q = tapq[(((size_t)f * 2 + (part >> 1)) * ks + dy) * ks + dx];
                         if (q > 32639 || q < -32639)

@@ -22,7 +22,7 @@ int gcs_hip_fail(hipError_t e, const char *what);
     } while (0)
 
 static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
-static inline int mtiles(int F) { return (F + 7) / 8; }
+static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles of a level: four filters each (csrc/abi.hip)
 
 // ------------------------------------------------------------------------ slab geometry
 // The feature slab keeps every pyramid level at its own resolution (SPEC.md §3). The image is cut into

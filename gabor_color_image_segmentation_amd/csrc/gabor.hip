@@ -45,6 +45,39 @@ __device__ __forceinline__ unsigned isqrt31(unsigned n) {
     return bits - 0x4B000000u + (unsigned)(d >> 31);
 }
 
+// The same root for the shift-8 epilogue of gabor_mfma_kernel, one instruction shorter: returns 0x4B000000 + floor(sqrt(n))
+// (the caller only keeps the low 16 bits) with the "- (qr^2 > n)" done by v_cmp_gt_u32 into an SGPR pair of the register
+// allocator's choice and v_subb_co_u32 (hipcc's own selection of this pattern goes through VCC, which chains the epilogues
+// of a scheduling region one behind the other). The two asm statements read and write only ordinary values (never an
+// accumulator register), and the kernel uses them only where every lane of every accumulator tuple is read, so the register
+// allocator has no dead accumulator lane to hand to an asm result while the matrix pipe still owes it a write (the round-2
+// bug described above). Checked over the whole domain by gcs_selftest_isqrt.
+__device__ __forceinline__ unsigned isqrt31_biased(unsigned n) {
+    const unsigned bits = __float_as_uint(__builtin_amdgcn_sqrtf((float)n) + 8388608.0f);
+    const unsigned sq = __umul24(bits, bits);
+    unsigned long long gt, carry_out;
+    unsigned q;
+    asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(gt) : "v"(sq), "v"(n));
+    asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q), "=s"(carry_out) : "v"(bits), "s"(gt));
+    return q;
+}
+// a_re^2 + a_im^2 of the packed pair (a_re | a_im << 16), both int16: v_dot2_i32_i16 in its three-address form (the
+// builtin selects the accumulating two-address form, which needs a zeroed destination first)
+__device__ __forceinline__ unsigned norm2_i16x2(unsigned p) {
+    unsigned n;
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(n) : "v"(p));
+    return n;
+}
+
+// the same squared norm by two v_mad_i32_i16 (low halves, then high halves through op_sel): two ordinary-rate
+// instructions where v_dot2_i32_i16 costs about two and a half beside a running MFMA chain (tools/ubench/mfma_beside)
+__device__ __forceinline__ unsigned norm2_i16x2_mad(unsigned p) {
+    unsigned lo, n;
+    asm("v_mad_i32_i16 %0, %1, %1, 0" : "=v"(lo) : "v"(p));
+    asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[1,1,0,0]" : "=v"(n) : "v"(p), "v"(lo));
+    return n;
+}
+
 // out[i] = 1 if isqrt31 is wrong anywhere in [i * chunk, (i+1) * chunk) ∩ [0, n_max] (test hook; SPEC.md §3 domain)
 __global__ void isqrt31_check_kernel(unsigned n_max, unsigned chunk, unsigned *__restrict__ bad) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,6 +86,7 @@ __global__ void isqrt31_check_kernel(unsigned n_max, unsigned chunk, unsigned *_
     for (unsigned long long n = lo; n < lo + chunk && n <= n_max; ++n) {
         const unsigned long long q = isqrt31((unsigned)n);
         wrong |= (q * q > n) | ((q + 1) * (q + 1) <= n);
+        wrong |= isqrt31_biased((unsigned)n) != (unsigned)q + 0x4B000000u;      // the epilogue's form of the same root
     }
     if (wrong) atomicAdd(bad, 1u);
 }
@@ -75,6 +109,7 @@ extern "C" int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_
 // Away from the borders the 4 pixels are 12 contiguous source bytes: they are fetched with unaligned dword loads (gfx950
 // global memory takes any byte alignment) and de-interleaved with v_perm_b32 (3 per channel dword).
 typedef unsigned __attribute__((aligned(1))) unaligned_u32;
+typedef short v2s __attribute__((ext_vector_type(2)));
 
 constexpr int GP_ROWS = 4;   // plane rows per thread: their loads are issued together (the kernel is latency-bound)
 
@@ -205,10 +240,22 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
 #ifndef GCS_GABOR_WAVES
 #define GCS_GABOR_WAVES 2
 #endif
-#ifndef GCS_GABOR_MTMAX_
-#define GCS_GABOR_MTMAX_ 2
+#ifndef GCS_GABOR_FAST
+#define GCS_GABOR_FAST 5      // shift-8 epilogue variant, bit mask (see epi_out); 0: every launch takes the general epilogue
 #endif
-constexpr int GCS_GABOR_MTMAX = GCS_GABOR_MTMAX_;   // row tiles per launch
+#ifndef GCS_GABOR_ABL
+#define GCS_GABOR_ABL 0       // timing ablations (tools/ab.py builds): 1 no stores, 2 trivial epilogue, 4 one MFMA per chain,
+#endif                       // 8 window read once per block, 16 no staging of further tiles. Results are wrong with any bit set.
+#ifndef GCS_GABOR_SLOTBAR
+#define GCS_GABOR_SLOTBAR 0   // scheduling barrier after every MFMA slot (0: one per chain; A/B builds)
+#endif
+#ifndef GCS_GABOR_ASMDMA
+#define GCS_GABOR_ASMDMA 1    // LDS-DMA through asm (0: the builtin; A/B builds)
+#endif
+#ifndef GCS_GABOR_MTMAX_
+#define GCS_GABOR_MTMAX_ 3
+#endif
+constexpr int GCS_GABOR_MTMAX = GCS_GABOR_MTMAX_;   // row tiles (of four filters) per launch; two for the 15-row frame
 
 // One pyramid level of a launch. Consecutive levels with the same filter count share ONE launch (tiles of level L, then
 // L+1, ... in one list): a level boundary then costs one reload of the A operand per workgroup instead of a kernel
@@ -225,22 +272,41 @@ struct GaborLevels {
     GaborLevel lv[GCS_LEVELS_MAX];
 };
 
-// MT row tiles of 8 filters each; GLAST = filter pairs (accumulator quads per half-wave) that exist in the last row
-// tile, so that the epilogue of absent filters is not even compiled (12 filters = MT 2, GLAST 2).
-// KS = K-steps of 2 tap rows: 8 for a 15-row frame, 7 when ksize <= 13 (its rows 1..13 of the frame: the last K-step
-// would multiply zeros).
-// FUSED = the tile list holds more than one level (otherwise every level field is a loop-invariant kernel argument:
-// same-box A/B, default bank, separate launches: 0.552 ms with the fields fixed, 0.566 ms with them reloaded per level).
-template <int MT, int GLAST, int KS, bool FUSED>
+// The bank of one level as an im2col GEMM on v_mfma_i32_32x32x32_i8 (round 3 layout).
+//   A rows  one 32-row tile = FOUR filters x {re_lo, re_hi, im_lo, im_hi} x TWO pixel shifts: row 8i + 4h + j is digit j of
+//           filter 2(i >> 1) + h of the tile, evaluated for the pixel (i & 1) to the right of the B column's pixel: the taps
+//           of that row sit one K-slot further right in the 16-slot frame row (gcs_bank_pack). A level's 12 filters are
+//           exactly MT = 3 tiles (round 2 padded them to 16), and the one-pixel shifts cost no instruction.
+//   K       K-step kk, half h, slot j = tap (dy = 2kk + h, dx = j) of the 16 x 16 frame, as before; KS = 7 K-steps when
+//           ksize <= 13 (frame rows 1..13), 8 for the 15-row frame.
+//   B cols  32 pixels (8 x 4): column (li, lyy) is the pixel PAIR x0 + 8li + 2pp (+0, +1), row row0 + lyy. Its fragment
+//           for K-step kk is the 16 window bytes starting at byte 8li + 2pp of tile row trow + 2kk + h. LDS holds the tile
+//           TWICE, the second copy shifted by two bytes (both written by LDS-DMA, the second from source address + 2), so
+//           every fragment is an aligned read of copy (pp & 1) at byte 8li + 4(pp >> 1): no v_alignbit / v_perm at all
+//           (round 2: 21 per pixel-shift step = a fifth of the kernel's VALU instructions).
+//   D       lane (n, h) holds rows 8i + 4h + j: both pixels of the pair for the two filters 2fp + h of the tile, i.e. one
+//           packed dword of the slab per (filter, pair) as before.
+// MT row tiles per launch (A operand = MT x KS lane-linear 16-byte fragments in registers), GQ = filter pairs that exist in
+// the last tile (the epilogue of absent filters is not compiled). LVL = the pyramid level of a single-level launch (0 or 1:
+// the store path of that level alone is compiled, every level field is a loop-invariant kernel argument), or -1 = FUSED: the
+// tile list may hold several levels and the level is a run-time value. FAST = the 11-instruction epilogue for shift == 8
+// (every Q15 bank) when all four accumulator quads of every tile are in use (GQ == 2); see `epilogue` below.
+// Per 4-row block a wave runs 4 MT chains of KS MFMAs (pair-major, tile-minor); chain t and the epilogue of chain t-1
+// share one scheduling region over two accumulator tuples, and the next pair's fragments are read from LDS while the
+// current pair's chains run.
+constexpr int G_COPY = 3 * G_LROWS * G_LPITCH;      // bytes of one copy of a tile (three channels)
+
+template <int MT, int GQ, int KS, int LVL, bool FAST>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, int bx_n, int ntiles,
     int tile_bytes) {
     // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
     // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
     // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
-    // 846 16-byte chunks, i.e. exactly the lane-linear destination LDS-DMA wants.
-    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][3][G_LROWS][G_LPITCH];
-    constexpr int NCHUNK = 3 * G_LROWS * (G_LPITCH / 16);
+    // 2 x 846 16-byte chunks, i.e. exactly the lane-linear destination LDS-DMA wants.
+    constexpr bool FUSED = LVL < 0;
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][2][3][G_LROWS][G_LPITCH];
+    constexpr int NCHUNK1 = G_COPY / 16, NCHUNK = 2 * NCHUNK1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -267,21 +333,31 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         for (int k = 0; k < (NCHUNK + 255) / 256; ++k) {
             const int i = tid + 256 * k;
             if (i < NCHUNK) {
-                const int ch16 = i % (G_LPITCH / 16), rc = i / (G_LPITCH / 16);
+                const int copy = i >= NCHUNK1, i1 = i - copy * NCHUNK1;
+                const int ch16 = i1 % (G_LPITCH / 16), rc = i1 / (G_LPITCH / 16);
                 const int row = rc % G_LROWS, c = rc / G_LROWS;
-                const int8_t *g = src0 + ((size_t)c * v.Hp + row) * v.Wp + 16 * ch16;
-                // LDS destination: wave-uniform base (this wave's first chunk) + lane * 16
-                int8_t *l = &s_tile[buf][0][0][0] + 16 * (256 * k + 64 * wave);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)g,
-                    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+                // the second copy is the same window read two bytes further right (LDS-DMA takes any source alignment)
+                const int8_t *g = src0 + ((size_t)c * v.Hp + row) * v.Wp + 16 * ch16 + 2 * copy;
+                // LDS destination: wave-uniform base (this wave's first chunk) in M0 + lane * 16. Issued as asm: hipcc models
+                // the builtin as a store to "some LDS" and then drains vmcnt - the DMA AND every feature store still in
+                // flight - in front of the next LDS read of the loop, i.e. at the top of every 4-row block (round 2 and the
+                // first round-3 build: waves parked in s_waitcnt a quarter of their cycles). The DMA only ever targets the
+                // buffer nobody reads before the barrier at the end of the tile, where vmcnt is drained explicitly.
+                const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t *)(&s_tile[buf][0][0][0][0]) +
+                                     16u * (unsigned)(256 * k + 64 * wave);
+#if GCS_GABOR_ASMDMA
+                unsigned m0_saved;             // M0 is reserved by hipcc: hand it back as it was
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_saved) : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(g));
+#else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(&s_tile[buf][0][0][0][0] + 16 * (256 * k + 64 * wave)), 16, 0, 0);
+                (void)lds;
+#endif
             }
         }
     };
 
-    // Pixel columns of one MFMA N-tile: x = x0 + 8*li + s (li = 0..7), y = row0 + lyy (lyy = 0..3),
-    // for a pixel shift s = 4*qq + t in 0..7. A lane therefore ends up owning 8 consecutive
-    // pixels (16 bytes) per filter: one row of an 8x8 block of the slab.
     const int r = lane & 31, h = lane >> 5;
     const int li = r & 7, lyy = r >> 3;
 
@@ -290,7 +366,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 
     // ---- per level: the whole A operand lives in registers (MT x KS lane-linear 16-byte fragments) with the biases
     v4i afr[MT][KS];
-    int bias_v[MT][4];
+    int bias_v[MT][2];
     int HL = 0, pitchL = 0, tiles_x = 1, tiles_per_image = 1, tile0 = 0, L = 0, offL = 0;
     int side_sh = 3, npl = KP_TP;          // slab geometry of the level (csrc/common.h): sub-block side 8 >> L, pixels per plane of a tile
     auto enter_level = [&](int lvl) {
@@ -303,10 +379,11 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias_v[mt][g] = v.bias[8 * mt + 2 * g + h];
+            for (int fp = 0; fp < 2; ++fp) bias_v[mt][fp] = v.bias[4 * mt + 2 * fp + h];
         HL = v.HL; pitchL = v.pitchL; tiles_x = v.tiles_x; tiles_per_image = v.tiles_per_image;
         tile0 = lvl ? pick(lvl - 1).tile_end : 0;
-        L = v.L; offL = v.offL;
+        L = LVL >= 0 ? LVL : v.L;
+        offL = v.offL;
         side_sh = 3 - L;
         npl = KP_TP >> (2 * L);
     };
@@ -315,7 +392,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     int lvl = FUSED ? -1 : 0, lvl_next = tile < total_tiles ? level_of(tile, 0) : 0;
     if constexpr (!FUSED) enter_level(0);
     if (tile < total_tiles) stage_tile(tile, lvl_next, 0);
-    __syncthreads();                       // drains the LDS-DMA (vmcnt) and orders it for every wave
+    // hipcc does not know about the DMA (asm): drain vmcnt by hand before every barrier that publishes a tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int it = 0; tile < total_tiles; tile += gridDim.x, ++it) {
       const int buf = it & 1;
       if constexpr (FUSED) {
@@ -326,123 +405,130 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
       }
       if (tile + (int)gridDim.x < total_tiles) {
           lvl_next = level_of(tile + gridDim.x, lvl);
-          stage_tile(tile + gridDim.x, lvl_next, buf ^ 1);
+          if (!(GCS_GABOR_ABL & 16)) stage_tile(tile + gridDim.x, lvl_next, buf ^ 1);
       }
       const int tl = tile - tile0;
       const int b = tl / tiles_per_image, trem = tl % tiles_per_image;
       const int y0 = (trem / tiles_x) * G_TH, x0 = (trem % tiles_x) * G_TW;
-      if (y0 + wave * 8 < HL) {            // waves wholly below the image skip the work, not the barrier
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll 1
-        for (int rb = 0; rb < 2; ++rb) {       // two 4-row blocks per wave
-            if (y0 + wave * 8 + rb * 4 >= HL) break;   // block wholly below the image (H = 321: 1 row in the last tile row)
-            const int trow = wave * 8 + rb * 4 + lyy;
-            unsigned outp[MT][4][4];
-            // The 8 pixel shifts s = 4*qq + t of this 4-row block. Step s runs its MFMA chain into one of two accumulator
-            // sets and the epilogue of step s-1 reads the other one, both inside one scheduling region, so hipcc can start
-            // the next chain before the previous step's magnitudes are finished (the matrix results it needs are long
-            // complete: no s_nop wait on the fresh chain). Forcing a fixed VALU/MFMA interleave with sched_group_barrier
-            // on top of this was slower (same-box A/B: 0.596 vs 0.569 ms per 64 images; profiles/r2_notes.md).
-            v16i acc[2][MT];
-            int win[KS][5];
-            auto load_window = [&](int qq) {
-                // 2*KS tap rows of this half-wave's parity x 20 bytes starting at 8*li + 4*qq
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    const int *rp = reinterpret_cast<const int *>(&s_tile[buf][c][trow + 2 * kk + h][8 * li + 4 * qq]);
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) win[kk][j] = rp[j];
-                }
-            };
-            auto epilogue = [&](const v16i (&ac)[MT], int qq, int t) {
-                // rows 4g..4g+3 of this lane = {re_lo, re_hi, im_lo, im_hi} of one filter
-                unsigned mag[MT][4];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (mt == MT - 1 && g >= GLAST) continue;
-                        // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22); the factor sits in an SGPR the
-                        // compiler cannot see through, or it turns the multiply into a left shift (2.3x slower here)
-                        const int v_re = __mul24(ac[mt][4 * g + 1], k256) + ac[mt][4 * g + 0] + bias_v[mt][g];
-                        const int v_im = __mul24(ac[mt][4 * g + 3], k256) + ac[mt][4 * g + 2];
-                        const int a_re = v_re >> shift, a_im = v_im >> shift;
-                        const unsigned n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
-                        mag[mt][g] = isqrt31(n);
-                    }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (mt == MT - 1 && g >= GLAST) continue;
-                        unsigned &o = outp[mt][g][2 * qq + (t >> 1)];
-                        if ((t & 1) == 0)
-                            o = mag[mt][g];
-                        else
-                            o = __umul24(mag[mt][g], k65536) + o;      // pack the odd pixel into the high half
-                        // materialise now: otherwise hipcc sinks the whole epilogue into the
-                        // store branches and keeps every accumulator live until then
-                        asm volatile("" : "+v"(o));
-                    }
-            };
-            load_window(0);
-#pragma unroll
-            for (int st = 0; st <= 8; ++st) {
-                const int qq = st >> 2, t = st & 3;
-                if (st < 8) {
-                    if (st == 4) load_window(1);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[st & 1][mt][e] = 0;   // inline-constant C of the first MFMA
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) {
-                        // B fragment of pixel shift s = 4qq + t: bytes [t, t+16) of the 20-byte window
-                        v4i bf;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            bf[j] = (t == 0) ? win[kk][j]
-                                             : (int)__builtin_amdgcn_alignbit((unsigned)win[kk][j + 1],
-                                                                              (unsigned)win[kk][j], 8 * t);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[st & 1][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], bf, acc[st & 1][mt], 0, 0, 0);
-                    }
-                }
-                if (st > 0) epilogue(acc[(st - 1) & 1], (st - 1) >> 2, (st - 1) & 3);
-                __builtin_amdgcn_sched_barrier(0);
+      // The wave's work in this tile: 4-row blocks (channel c, row block rb), a software pipeline over ALL of them: every
+      // block is 4 MT chains of KS MFMAs (pixel pair pp, tile mt); chain t shares its scheduling region with the epilogue of
+      // chain t-1 - for the first chain of a block that is the LAST chain of the previous block, whose stores follow it - and
+      // the fragments of the next pixel pair (for the last pair: of the next block) are read from LDS one pair ahead. Round 2
+      // and the first round-3 build drained the pipeline at every block: a region of MFMAs alone, a region of VALU alone and
+      // an exposed LDS read per block.
+      const bool rows1 = y0 + wave * 8 + 4 < HL;                    // both row blocks of this wave hold image rows
+      const int nblk = y0 + wave * 8 < HL ? (rows1 ? 6 : 3) : 0;    // waves wholly below the image skip the work, not the barrier
+      if (nblk) {
+        unsigned outp[MT][2][4];           // [tile][filter pair][pixel pair]: two uint16 magnitudes each
+        v16i acc[2];
+        v4i win[KS];                       // the fragments of ONE pixel pair, refilled behind the last chain that reads them
+        int c = 0, trow = wave * 8 + lyy;                            // current block
+        int st_c = 0, st_trow = 0;                                   // the block whose results are in outp
+        // fragment kk of pixel pair pp = 2 qq + copy of block (wc, wtrow): 16 bytes of copy `copy` at byte 8 li + 4 qq of
+        // tap row 2 kk + h (this half-wave's parity)
+        auto load_fragment = [&](int kk, int wc, int wtrow, int copy, int qq) -> v4i {
+            const int8_t *rp = &s_tile[buf][copy][wc][wtrow + 2 * kk + h][8 * li];
+            if (GCS_GABOR_ABL & 32) {          // timing ablation: fragments made up by four VALU instructions, no LDS read
+                const int a = (int)(size_t)rp;
+                return v4i{a + qq, a ^ 0x55, a + 7, a ^ kk};
             }
+            if (qq == 0) {
+                const v2i lo = *reinterpret_cast<const v2i *>(rp), hi = *reinterpret_cast<const v2i *>(rp + 8);
+                return v4i{lo[0], lo[1], hi[0], hi[1]};
+            }
+            const int *dp = reinterpret_cast<const int *>(rp + 4);    // 4-byte aligned: dword reads straight into the registers
+            return v4i{dp[0], dp[1], dp[2], dp[3]};
+        };
+        // One output of the epilogue: accumulator quad i = 2 fp + sx of a finished chain = {re_lo, re_hi, im_lo, im_hi} of filter
+        // 2 fp + h of the tile at pixel 2 pp + sx -> its magnitude (FAST: plus 0x4B000000, dropped when the pair is packed).
+        auto epi_out = [&](const v16i &ac, int mt, int fp, int sx) -> unsigned {
+            const int i = 2 * fp + sx;
+            if constexpr ((GCS_GABOR_ABL & 2) != 0) {
+                return (unsigned)(ac[4 * i] ^ ac[4 * i + 1] ^ ac[4 * i + 2] ^ ac[4 * i + 3]);
+            } else if constexpr (FAST) {
+                // a = (256 H + L + bias) >> 8 = H + ((L + bias) >> 8), |a| < 2^15 (gcs_bank_pack bounds sum |tapq|), so
+                // the low 16 bits of H and bytes 1-2 of L + bias add up to a in 16-bit arithmetic: one v_perm packs
+                // (H_re, H_im), one packs and shifts (L_re + bias, L_im), v_pk_add_u16 gives (a_re | a_im << 16), then the
+                // squared norm of the pair and the root. GCS_GABOR_FAST picks the instructions (A/B builds): bit 0 the
+                // v_cmp / v_subb root tail, bit 1 v_dot2 for the norm (else two v_mad_i32_i16), bit 2 the packed front end
+                // (else the general v_mad_i32_i24 / shift / v_mul_i32_i24 front end with only the tail changed).
+                unsigned n;
+                if constexpr ((GCS_GABOR_FAST & 4) != 0) {
+                    const unsigned ph = __builtin_amdgcn_perm((unsigned)ac[4 * i + 3], (unsigned)ac[4 * i + 1], 0x05040100u);
+                    const unsigned pl = __builtin_amdgcn_perm((unsigned)ac[4 * i + 2], (unsigned)(ac[4 * i + 0] + bias_v[mt][fp]), 0x06050201u);
+                    const v2s pa = __builtin_bit_cast(v2s, ph) + __builtin_bit_cast(v2s, pl);
+                    n = (GCS_GABOR_FAST & 2) ? norm2_i16x2(__builtin_bit_cast(unsigned, pa)) : norm2_i16x2_mad(__builtin_bit_cast(unsigned, pa));
+                } else {
+                    const int v_re = __mul24(ac[4 * i + 1], k256) + ac[4 * i + 0] + bias_v[mt][fp];
+                    const int v_im = __mul24(ac[4 * i + 3], k256) + ac[4 * i + 2];
+                    const int a_re = v_re >> 8, a_im = v_im >> 8;
+                    n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
+                }
+                return (GCS_GABOR_FAST & 1) ? isqrt31_biased(n) : isqrt31(n) + 0x4B000000u;
+            } else {
+                // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22); the factor sits in an SGPR the
+                // compiler cannot see through, or it turns the multiply into a left shift (2.3x slower here)
+                const int v_re = __mul24(ac[4 * i + 1], k256) + ac[4 * i + 0] + bias_v[mt][fp];
+                const int v_im = __mul24(ac[4 * i + 3], k256) + ac[4 * i + 2];
+                const int a_re = v_re >> shift, a_im = v_im >> shift;
+                return isqrt31((unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im));
+            }
+        };
+        // the two pixels of a pair -> one dword of the slab: offset-binary (x ^ 0x8080: both bytes are then signed MFMA digits
+        // for the k-means pass, which stages them untouched), the odd pixel in the high half
+        auto epi_pack = [&](unsigned q0, unsigned q1, int mt, int fp, int pp) {
+            unsigned &o = outp[mt][fp][pp];
+            if constexpr (FAST) o = __builtin_amdgcn_perm(q1, q0, 0x05040100u);   // low halves: the 0x4B000000 bias drops out
+            else o = __umul24(q1, k65536) + q0;
+            o ^= 0x80808080u;
+            asm volatile("" : "+v"(o));     // materialise now: hipcc otherwise sinks the packing into the store branches
+        };
+        // Slice `slot` (= the K-step the chain in flight is at) of the epilogue of finished chain (mt, pp): slots 1..4 one
+        // output each, slot 5 the packing; slot 0 leaves the last MFMA of the finished chain time to land.
+        unsigned qv[4];
+        auto epi_slice = [&](const v16i &ac, int mt, int pp, int slot) {
+            const bool two = !(mt == MT - 1 && GQ == 1);          // both filter pairs of this tile exist
+            if (slot >= 1 && slot <= 4) {
+                const int fp = (slot - 1) >> 1, sx = (slot - 1) & 1;
+                if (fp == 0 || two) qv[slot - 1] = epi_out(ac, mt, fp, sx);
+            } else if (slot == 5) {
+                epi_pack(qv[0], qv[1], mt, 0, pp);
+                if (two) epi_pack(qv[2], qv[3], mt, 1, pp);
+            }
+        };
+        auto store_block = [&]() {
             // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy. Level 0: one row of one 8x8 block = one 16-byte
             // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels).
-            const int oy = y0 + trow, ox = x0 + 8 * li;
-            if (oy < HL && ox < pitchL) {
-                const int by = oy >> side_sh, iy = oy & ((1 << side_sh) - 1);
-                const int bx0 = ox >> side_sh;
+            // compile-time geometry for single-level launches
+            const int Lc = LVL >= 0 ? LVL : L, ssh = LVL >= 0 ? 3 - LVL : side_sh, nplc = LVL >= 0 ? (KP_TP >> (2 * (LVL >= 0 ? LVL : 0))) : npl;
+            const int oy = y0 + st_trow, ox = x0 + 8 * li;
+            if ((GCS_GABOR_ABL & 1) && oy == -12345) feats[lane] = (unsigned char)(outp[0][0][0] ^ outp[MT - 1][GQ - 1][3]);
+            if (!(GCS_GABOR_ABL & 1) && oy < HL && ox < pitchL) {
+                const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
+                const int bx0 = ox >> ssh;
                 // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
                 // target block (tile of the block, block inside the tile, row inside the block, filter parity h), so that a
                 // store costs no vector address arithmetic (global_store with an SGPR base).
-                unsigned char *ubase = feats + (size_t)b * ntiles * tile_bytes + offL + (size_t)(c * FLv + fbase) * npl * 2;
-                const unsigned row_off = (unsigned)(((iy << side_sh) + h * npl) * 2);
+                unsigned char *ubase = feats + (size_t)b * ntiles * tile_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
+                const unsigned row_off = (unsigned)(((iy << ssh) + h * nplc) * 2);
                 auto lane_off = [&](int p) -> unsigned {           // block bx0 + p, this lane's row inside it
                     const int blk = by * bx_n + bx0 + p;
-                    return (unsigned)(blk >> 2) * (unsigned)tile_bytes + (unsigned)((blk & 3) << (2 * side_sh)) * 2u + row_off;
+                    return (unsigned)(blk >> 2) * (unsigned)tile_bytes + (unsigned)((blk & 3) << (2 * ssh)) * 2u + row_off;
                 };
                 auto planes = [&](auto &&put) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (mt == MT - 1 && g >= GLAST) continue;
+                        for (int fp = 0; fp < 2; ++fp) {
+                            if (mt == MT - 1 && fp >= GQ) continue;
                             // an odd filter count leaves the h = 1 half of the LAST pair without a filter
-                            const bool last = mt == MT - 1 && g == GLAST - 1;
-                            if (last && fbase + 8 * mt + 2 * g + h >= FLv) continue;
-                            // the slab holds offset-binary features (x ^ 0x8080): both bytes are then
-                            // signed MFMA digits for the k-means pass, which stages them untouched
-                            put(ubase + (size_t)(8 * mt + 2 * g) * npl * 2, outp[mt][g][0] ^ 0x80808080u,
-                                outp[mt][g][1] ^ 0x80808080u, outp[mt][g][2] ^ 0x80808080u, outp[mt][g][3] ^ 0x80808080u);
+                            const bool last = mt == MT - 1 && fp == GQ - 1;
+                            if (last && fbase + 4 * mt + 2 * fp + h >= FLv) continue;
+                            put(ubase + (size_t)(4 * mt + 2 * fp) * nplc * 2, outp[mt][fp][0], outp[mt][fp][1], outp[mt][fp][2],
+                                outp[mt][fp][3]);
                         }
                 };
-                if (L == 0) {
+                if (Lc == 0) {
                     // nontemporal: the slab (0.9 GB per 64 images) is read back only by the Lloyd passes; plain stores
                     // leave ~0.3 GB of it dirty in L2 / Infinity Cache and the first pass then shares HBM with their
                     // write-back (same-box A/B: first pass 0.219 -> 0.186 ms, step -2 %)
@@ -450,14 +536,14 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
                     });
-                } else if (L == 1) {
+                } else if (Lc == 1) {
                     const unsigned o0 = lane_off(0), o1 = lane_off(1);
                     const bool has1 = bx0 + 1 < bx_n;
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o0));
                         if (has1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o1));
                     });
-                } else if (L == 2) {
+                } else if (Lc == 2) {
                     unsigned o[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) o[p] = lane_off(p);
@@ -480,9 +566,56 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     });
                 }
             }
+        };
+        constexpr int NT = 4 * MT;
+        static_assert(NT % 2 == 0, "the accumulator ring must close over a block");
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) win[kk] = load_fragment(kk, 0, trow, 0, 0);
+#pragma unroll 1
+        for (int j = 0; j < nblk; ++j) {
+            // next block (for the fragments of its first pixel pair; past the end: any valid address)
+            const int jn = j + 1 < nblk ? j + 1 : 0;
+            const int cn = rows1 ? jn >> 1 : jn, trown = wave * 8 + (rows1 ? (jn & 1) * 4 : 0) + lyy;
+            // chain t = (window step ws, tile mt); window steps in the order (copy 0, qq 0), (copy 0, qq 1), (copy 1, qq 0),
+            // (copy 1, qq 1): pixel pair pp = 2 qq + copy. The last chain of a window step refills every fragment register
+            // right behind the MFMA that read it, with the fragment of the next step (of the next block after the last
+            // step): one chain of lead for an LDS read, and one set of fragment registers instead of two.
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ws = t / MT, mt = t % MT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t & 1][e] = 0;   // inline-constant C of the first MFMA
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    // slot kk of the region: one MFMA of chain t, the refill of the fragment it has just read (last chain of a
+                    // window step), one slice of the epilogue of chain t-1 - for the first chain of a block that is the LAST
+                    // chain of the previous block, whose stores follow it. The scheduling barrier after every slot keeps the
+                    // MFMAs evenly spaced and the LDS reads behind the MFMA that frees their registers (hoisted, they need a
+                    // second set of fragment registers: 22 spilled VGPRs at MT = 3).
+                    if (!((GCS_GABOR_ABL & 4) && kk > 0))
+                        acc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], win[kk], acc[t & 1], 0, 0, 0);
+                    if (mt == MT - 1 && !(GCS_GABOR_ABL & 8))
+                        win[kk] = ws < 3 ? load_fragment(kk, c, trow, (ws + 1) >> 1, (ws + 1) & 1) : load_fragment(kk, cn, trown, 0, 0);
+                    if (t > 0) {
+                        const int wp = (t - 1) / MT;
+                        epi_slice(acc[(t - 1) & 1], (t - 1) % MT, 2 * (wp & 1) + (wp >> 1), kk);
+                    } else if (j > 0) {
+                        epi_slice(acc[(NT - 1) & 1], MT - 1, 3, kk);
+                    }
+                    if (GCS_GABOR_SLOTBAR || kk == KS - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == 0 && j > 0) store_block();
+            }
+            st_c = c;
+            st_trow = trow;
+            c = cn;
+            trow = trown;
         }
-    }
+#pragma unroll
+        for (int slot = 1; slot <= 5; ++slot) epi_slice(acc[(NT - 1) & 1], MT - 1, 3, slot);
+        store_block();
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed in LDS
       __syncthreads();   // next tile landed (vmcnt drained) and this buffer is free to refill
     }
 }
@@ -515,7 +648,7 @@ static GaborWs gabor_ws(int B, int H, int W, int n_levels) {
         h = (h + 1) / 2;
         w = (w + 1) / 2;
     }
-    ws.total = off;
+    ws.total = off + 256;   // the second LDS copy of the last tile row reads two bytes past its plane row
     return ws;
 }
 
@@ -635,6 +768,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         mt_base[L] = m;
         m += mtiles(lo.FL[L]);
     }
+    const int mtmax = ksize <= 13 ? GCS_GABOR_MTMAX : 2;     // A operand: MT x KS x 4 VGPRs (84 for 3 x 7, 64 for 2 x 8)
     for (int L0 = 0; L0 < lo.n_levels;) {
         int L1 = L0 + 1;
         // fused lists pay ~2 % for level fields that are no longer launch constants and win the small levels' ramp and
@@ -644,18 +778,22 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         const int FLg = lo.FL[L0], MT = mtiles(FLg);
         if (L0 == 0 && L1 > 1)                       // this launch reads planes the side stream is still writing
             if (int rc = join()) return rc;
-        for (int mt0 = 0; mt0 < MT; mt0 += GCS_GABOR_MTMAX) {
-            const int n = MT - mt0 >= GCS_GABOR_MTMAX ? GCS_GABOR_MTMAX : MT - mt0;
-            // filters of this launch: [8*mt0, min(FL, 8*(mt0+n))) of each level (planes c*FL + f)
-            const int fl_here = FLg - 8 * mt0 < 8 * n ? FLg - 8 * mt0 : 8 * n;
-            const int glast = (fl_here - 8 * (n - 1) + 1) / 2;
+        // three row tiles only for single launches of level 0 / 1 (compile-time level): with the level a run-time value the
+        // store path of every level is live and a third tile's 28 A registers spill
+        const int mtmax_here = (L1 - L0 == 1 && L0 <= 1) ? mtmax : 2;
+        const int passes = (MT + mtmax_here - 1) / mtmax_here, per_pass = (MT + passes - 1) / passes;   // 4 tiles -> 2 + 2, not 3 + 1
+        for (int mt0 = 0; mt0 < MT; mt0 += per_pass) {
+            const int n = MT - mt0 >= per_pass ? per_pass : MT - mt0;
+            // filters of this launch: [4*mt0, min(FL, 4*(mt0+n))) of each level (planes c*FL + f)
+            const int fl_here = FLg - 4 * mt0 < 4 * n ? FLg - 4 * mt0 : 4 * n;
+            const int gq = (fl_here - 4 * (n - 1) + 1) / 2;
             GaborLevels G{};
             long long total_ll = 0;
             for (int L = L0; L < L1; ++L) {
                 GaborLevel &v = G.lv[L - L0];
                 v.planes = reinterpret_cast<const int8_t *>(wsb + ws.plane_off[L]);
                 v.apack = packed + (size_t)(mt_base[L] + mt0) * 8 * 64 * 16;
-                v.bias = bias + (size_t)(mt_base[L] + mt0) * 8;
+                v.bias = bias + (size_t)(mt_base[L] + mt0) * 4;
                 v.HL = ws.HL[L];
                 v.Hp = ws.Hp[L];
                 v.Wp = ws.Wp[L];
@@ -673,41 +811,42 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 G.lv[i].tile_end = 0x7fffffff;
             }
             const int total_tiles = (int)total_ll;
-            // persistent grid: one workgroup per resident slot (2 per CU at MT >= 2, 3 at MT == 1)
-            const int slots = 256 * (n == 1 ? 3 : 2);
+            // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
+            const int slots = 256 * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
-#define GCS_GABOR_LAUNCH4(MT_, GL_, KS_, FU_)                                                                            \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GL_, KS_, FU_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 8 * mt0, shift,  \
+#define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
                        reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
-#define GCS_GABOR_LAUNCH3(MT_, GL_, KS_)                             \
-    do {                                                             \
-        if (L1 - L0 > 1) GCS_GABOR_LAUNCH4(MT_, GL_, KS_, true);     \
-        else GCS_GABOR_LAUNCH4(MT_, GL_, KS_, false);                \
+            // single launches of level 0 / level 1 (every bank of at most two levels) compile that level's store path alone
+#define GCS_GABOR_LAUNCH3(MT_, GQ_, KS_, FA_)                                       \
+    do {                                                                            \
+        if (L1 - L0 == 1 && L0 == 0) GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, 0, FA_);      \
+        else if (L1 - L0 == 1 && L0 == 1) GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, 1, FA_); \
+        else GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, -1, FA_);                             \
+    } while (0)
+            // the short epilogue needs shift == 8 (bytes 1-2 of the low accumulator) and no unused accumulator quad
+#define GCS_GABOR_LAUNCH2(MT_, KS_)                                       \
+    do {                                                                  \
+        if (gq == 1) GCS_GABOR_LAUNCH3(MT_, 1, KS_, false);               \
+        else if (shift == 8 && GCS_GABOR_FAST != 0) GCS_GABOR_LAUNCH3(MT_, 2, KS_, true); \
+        else GCS_GABOR_LAUNCH3(MT_, 2, KS_, false);                       \
     } while (0)
             // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
-#define GCS_GABOR_LAUNCH(MT_, GL_)                                   \
-    do {                                                             \
-        if (ksize <= 13) GCS_GABOR_LAUNCH3(MT_, GL_, 7);             \
-        else GCS_GABOR_LAUNCH3(MT_, GL_, 8);                         \
-    } while (0)
-            if (n == 2) {
-                switch (glast) {
-                case 1: GCS_GABOR_LAUNCH(2, 1); break;
-                case 2: GCS_GABOR_LAUNCH(2, 2); break;
-                case 3: GCS_GABOR_LAUNCH(2, 3); break;
-                default: GCS_GABOR_LAUNCH(2, 4); break;
+            if (ksize <= 13) {
+                if (n == 3) {                    // single launch of level 0 or 1 (mtmax_here)
+                    if (gq == 1) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 1, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 1, 7, 1, false); }
+                    else if (shift == 8 && GCS_GABOR_FAST != 0) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, true); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, true); }
+                    else { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, false); }
                 }
+                else if (n == 2) GCS_GABOR_LAUNCH2(2, 7);
+                else GCS_GABOR_LAUNCH2(1, 7);
             } else {
-                switch (glast) {
-                case 1: GCS_GABOR_LAUNCH(1, 1); break;
-                case 2: GCS_GABOR_LAUNCH(1, 2); break;
-                case 3: GCS_GABOR_LAUNCH(1, 3); break;
-                default: GCS_GABOR_LAUNCH(1, 4); break;
-                }
+                if (n == 2) GCS_GABOR_LAUNCH2(2, 8);
+                else GCS_GABOR_LAUNCH2(1, 8);
             }
 #undef GCS_GABOR_LAUNCH4
 #undef GCS_GABOR_LAUNCH3
-#undef GCS_GABOR_LAUNCH
+#undef GCS_GABOR_LAUNCH2
             GCS_GABOR_CHECK("gcs_gabor_features");
         }
         L0 = L1;

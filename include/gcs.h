@@ -37,6 +37,7 @@ enum {
 #define GCS_ABI_VERSION 13
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
+#define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
 #define GCS_SCALES_MAX 8  /* octave pyramid of at most 4 levels: scales 2L, 2L+1 run on level L (SPEC.md §2) */
 
 int gcs_abi_version(void);

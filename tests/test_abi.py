@@ -40,9 +40,9 @@ def test_geometry(lib):
     assert lib.gcs_feature_slab_bytes(1, 321, 481, 7, 1) == tiles * (6 * 512 + 6 * 128 + 6 * 32 + 32)   # 3 planes x 4 px x 2 B = 24 -> 32
     assert lib.gcs_feature_slab_bytes(1, 8, 8, 1, 1) == 3 * 512
     assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * tiles * 256
-    assert lib.gcs_bank_packed_bytes(4, 6) == 4 * 8 * 64 * 16          # 12 filters per level -> 2 row tiles each
-    assert lib.gcs_bank_packed_bytes(1, 1) == 8 * 64 * 16 and lib.gcs_bank_packed_bytes(8, 8) == 8 * 8 * 64 * 16
-    assert lib.gcs_bank_bias_count(4, 6) == 32 and lib.gcs_bank_bias_count(3, 9) == 24 + 16
+    assert lib.gcs_bank_packed_bytes(4, 6) == 6 * 8 * 64 * 16          # 12 filters per level -> 3 row tiles of 4 filters each
+    assert lib.gcs_bank_packed_bytes(1, 1) == 8 * 64 * 16 and lib.gcs_bank_packed_bytes(8, 8) == 16 * 8 * 64 * 16
+    assert lib.gcs_bank_bias_count(4, 6) == 24 and lib.gcs_bank_bias_count(3, 9) == 20 + 12
     assert lib.gcs_bank_packed_bytes(9, 1) == 0 and lib.gcs_bank_packed_bytes(0, 1) == 0
     p = lib.gcs_kmeans_parts_per_image(64, 321, 481)
     assert p == 12 and tiles * 256 / p <= 65536                # 64 * 12 = 768 workgroups = 256 CUs x 3
@@ -67,15 +67,16 @@ def _pack(lib, bank):
 @pytest.mark.parametrize("kw", [{}, dict(n_scales=2, n_orient=3, ksize=7), dict(n_scales=1, n_orient=1, ksize=1),
                                 dict(n_scales=8, n_orient=8), dict(n_scales=3, n_orient=9, ksize=9)])
 def test_bank_pack_layout(lib, kw):
-    """Level by level (filters of scales 2L, 2L+1), each level on fresh row tiles:
-    packed[tile][kk][lane][j] = digit(part) of tap (dy=2kk+h, dx=j) of the level's filter 8mt + r/4 (csrc/abi.hip)."""
+    """Level by level (filters of scales 2L, 2L+1), each level on fresh row tiles of FOUR filters: row 8i + 4hh + part of
+    tile mt is digit `part` of the level's filter 4mt + 2(i >> 1) + hh with its taps s = i & 1 slots to the right:
+    packed[tile][kk][lane][j] = digit of tap (dy = 2kk + h, dx = j - s) (csrc/abi.hip)."""
     bank = make_bank(**kw)
     rc, packed, bias = _pack(lib, bank)
     assert rc == 0
     nf, ks, no = bank.n_filters, bank.ksize, bank.n_orient
     lo, hi = split_digits(bank.tapq)
     off = (15 - ks) // 2
-    frame = np.zeros((nf, 4, 16, 16), np.int8)           # part order: re_lo, re_hi, im_lo, im_hi
+    frame = np.zeros((nf, 4, 16, 17), np.int8)           # part order: re_lo, re_hi, im_lo, im_hi; one spare column for the shift
     for part, (dig, ri) in enumerate([(lo, 0), (hi, 0), (lo, 1), (hi, 1)]):
         frame[:, part, off:off + ks, off:off + ks] = dig[:, ri]
     pk = packed.reshape(-1, 8, 64, 16)
@@ -83,17 +84,20 @@ def test_bank_pack_layout(lib, kw):
     for lv in range(bank.n_levels):
         f0 = 2 * lv * no
         fl_n = min(nf, f0 + 2 * no) - f0
-        mt_n = (fl_n + 7) // 8
+        mt_n = (fl_n + 3) // 4
         for mt in range(mt_n):
             for kk in range(8):
-                for lane in (0, 1, 5, 31, 32, 47, 63):
+                for lane in range(64):
                     r, h = lane & 31, lane >> 5
-                    fl, part = 8 * mt + r // 4, r & 3
-                    want = frame[f0 + fl, part, 2 * kk + h] if fl < fl_n else np.zeros(16, np.int8)
+                    i, hh, part = r >> 3, (r >> 2) & 1, r & 3
+                    fl, s = 4 * mt + 2 * (i >> 1) + hh, i & 1
+                    want = np.zeros(16, np.int8)
+                    if fl < fl_n:
+                        want[s:] = frame[f0 + fl, part, 2 * kk + h, :16 - s]
                     assert np.array_equal(pk[tile0 + mt, kk, lane], want)
-        want_bias = np.zeros(8 * mt_n, np.int64)
+        want_bias = np.zeros(4 * mt_n, np.int64)
         want_bias[:fl_n] = 128 * bank.tapq[f0:f0 + fl_n, 0].astype(np.int64).sum(axis=(1, 2))
-        assert np.array_equal(bias[8 * tile0:8 * (tile0 + mt_n)], want_bias)
+        assert np.array_equal(bias[4 * tile0:4 * (tile0 + mt_n)], want_bias)
         tile0 += mt_n
     assert tile0 == pk.shape[0]
 

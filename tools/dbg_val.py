@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Debug: features of the packed BSD val images on the GPU (batched, as the gate test runs them) against the C oracle;
+repeats the GPU run to tell a deterministic error from a race. usage: dbg_val.py [repeats]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gabor_color_image_segmentation_amd import Segmenter
+from oracle import spec_oracle as so, c_oracle as co
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+pack = np.load(os.path.join(ROOT, "tests/golden/bsd_val_images.npz"))
+ids = [str(i) for i in pack["ids"]]
+seg = Segmenter()
+tapq, shift = so.bank()
+for shape in ((321, 481), (481, 321)):
+    group = [i for i in ids if pack["img_" + i].shape[:2] == shape]
+    imgs = np.stack([pack["img_" + i] for i in group])
+    ref = np.stack([co.gabor_features(im, tapq.astype(np.int16), shift, 6) for im in imgs])
+    dev = torch.from_numpy(imgs).cuda()
+    for r in range(reps):
+        got = seg.features_device(dev).cpu().numpy().view(np.uint16)
+        bad = np.argwhere(got != ref)
+        print(shape, "rep", r, "bad", len(bad), "of", got.size)
+        if len(bad):
+            b, d, y, x = bad.T
+            print("  images", np.unique(b), "planes", np.unique(d)[:24], "x%8", np.bincount(x % 8, minlength=8), "y%8", np.bincount(y % 8, minlength=8))
+            print("  y range", y.min(), y.max(), "x range", x.min(), x.max(), " y//32", np.unique(y // 32)[:20], " x//64", np.unique(x // 64))
+            for q in bad[:5]:
+                print("   ", q, got[tuple(q)], ref[tuple(q)])
