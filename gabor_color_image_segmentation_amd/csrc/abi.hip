@@ -13,6 +13,19 @@ int gcs_hip_fail(hipError_t e, const char *what) {
     return GCS_EHIP;
 }
 
+int gcs_cu_count() {
+    static int cached[64];                                   // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cached[dev] = prop.multiProcessorCount;
+        else { (void)hipGetLastError(); cached[dev] = 256; }
+    }
+    return cached[dev];
+}
+extern "C" int gcs_device_cu_count(void) { return gcs_cu_count(); }
+
 extern "C" int gcs_abi_version(void) { return GCS_ABI_VERSION; }
 extern "C" const char *gcs_last_error(void) { return g_err; }
 

@@ -21,6 +21,10 @@ int gcs_hip_fail(hipError_t e, const char *what);
         if (e_ != hipSuccess) return gcs_hip_fail(e_, what); \
     } while (0)
 
+// Compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): sizes the persistent grids.
+// 256 on an MI355X in SPX mode, the machine the launch geometry was tuned on; a partitioned device reports fewer.
+int gcs_cu_count();
+
 static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles of a level: four filters each (csrc/abi.hip)
 

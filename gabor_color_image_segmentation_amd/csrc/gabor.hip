@@ -29,7 +29,7 @@ __device__ __forceinline__ int reflect(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
-// floor(sqrt(n)) for n < 2^31 (SPEC.md §3 bound: n <= 2 * 32724^2), exact, in 7 VALU ops:
+// floor(sqrt(n)) for n < 2^31 (SPEC.md §3: n <= 2 * 32767^2, kept by gcs_bank_pack's bound on sum |tapq|), exact, in 7 VALU ops:
 //   r    = v_sqrt_f32(float(n))        |r - s| <= 1.5e-7 * s <= 0.007 < 0.5   (s = true root)
 //   bits = r + 2^23 (as uint)          the sum has ulp 1: bits = 0x4B000000 + RNE(r), RNE(r) in {floor(s), floor(s)+1}
 //   qr^2 = v_mul_u32_u24(bits, bits)   the multiplier only sees the low 24 bits, i.e. qr = RNE(r) (< 2^16)
@@ -713,7 +713,12 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     // batches stay on one stream too.
     GaborSide *sd = nullptr;
     std::unique_lock<std::mutex> side_lock;
-    if (lo.n_levels == 2 && (long long)B * H * W >= GCS_GABOR_FORK_MIN_PIXELS) {
+    // Not while the caller's stream is being captured into a graph: the process-wide side stream would join that capture and
+    // stay in capture mode until the caller ends it, long after the mutex below is released (a concurrent call from another
+    // thread would then enqueue into a foreign capture). A captured step runs its levels on the one stream.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (lo.n_levels == 2 && (long long)B * H * W >= GCS_GABOR_FORK_MIN_PIXELS && cap == hipStreamCaptureStatusNone) {
         side_lock = std::unique_lock<std::mutex>(g_side_mu);     // the fork / join events are reused: one enqueue at a time
         sd = gabor_side();
         if (!sd) side_lock.unlock();
@@ -812,7 +817,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             }
             const int total_tiles = (int)total_ll;
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
-            const int slots = 256 * 2;
+            const int slots = gcs_cu_count() * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \

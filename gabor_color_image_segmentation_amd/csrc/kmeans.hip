@@ -1076,6 +1076,25 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, con
     return GCS_OK;
 }
 
+// Working workgroups per image of the native pass: two 4-wave workgroups per CU are resident, so at most 512 / B of the
+// `parts` workgroups of an image work (the others only write zero rows) - but never so few that a wave's int32 MFMA
+// accumulators can overflow: they are flushed only at the end of the pass, a voting pixel adds up to 128 * 128 to one of
+// them and a wave sees a quarter of its workgroup's pixels, so a workgroup may own at most 2^31 / 2^14 * 4 = 524 288 pixels;
+// the bound used is half of that. (`parts` itself keeps a workgroup below 65 536 pixels: gcs_kmeans_parts_per_image.)
+constexpr long long NV_MAX_PX_PER_WORKGROUP = 262144;
+static int native_parts_eff(int B, int parts, long long px_image) {
+    int eff = 512 / B > 0 ? 512 / B : 1;
+    const long long need = (px_image + NV_MAX_PX_PER_WORKGROUP - 1) / NV_MAX_PX_PER_WORKGROUP;
+    if (eff < need) eff = (int)need;
+    return eff < parts ? eff : parts;
+}
+// Test hook (host only): the working workgroups per image the native pass would use, 0 for a bad shape.
+extern "C" int gcs_selftest_native_parts(int B, int H, int W) {
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
+    return native_parts_eff(B, (int)gcs_kmeans_parts_per_image(B, H, W), (long long)lo.ntiles * KP_TP);
+}
+
 extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
                                             int n_scales, int n_orient, int k, int n_sets, int row_lo, int row_hi,
                                             int reverse, uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
@@ -1118,7 +1137,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 #endif
             if (native) {
                 // two 4-wave workgroups per CU are resident: 512 of the workgroups work, the others write zero partial rows
-                const int parts_eff = parts < 512 / B ? parts : (512 / B > 0 ? 512 / B : 1);
+                const int parts_eff = native_parts_eff(B, parts, (long long)lo.ntiles * KP_TP);
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
     hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \

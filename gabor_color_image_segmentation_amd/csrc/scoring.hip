@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__res
     area += (size_t)b * n_seg;
     perim += (size_t)b * n_seg;
     const int n_hist = a_n * n_seg * stride, n_tab = n_hist + 2 * n_seg;
+    // the dynamic LDS was sized by the host for A annotators per image: an image that brings more (a caller that understated
+    // max_annotators) takes the global-atomics path instead of writing past its allocation
+    use_lds = use_lds && a_n <= A;
     if (use_lds) {
         for (int i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = 0u;
         __syncthreads();

@@ -235,15 +235,22 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
                 ops.finalize(sums, n_sets, k, cent)
 
 
-def shard_rows(height: int, world: int, rank: int, n_levels: int = 2):
+def halo_rows(n_levels: int = 2, ksize: int = 15) -> int:
+    """Real neighbour rows an interior strip edge needs: the reach (ksize - 1) / 2 of the coarsest level's kernel in
+    full-resolution rows (12 for the default 13x13 bank on two levels, 14 for a 15x15 one)."""
+    return ((ksize - 1) // 2) << (n_levels - 1)
+
+
+def shard_rows(height: int, world: int, rank: int, n_levels: int = 2, ksize: int = 15):
     """Row strip of rank ``rank``: owned global rows [r0, r1) and the strip [s0, s1) that also carries real
     neighbour rows on interior edges (BASELINE config 5).
 
-    ``n_levels`` = pyramid levels of the bank (SPEC.md §2; 2 for the default 4-scale bank). Strip and ownership
-    boundaries are multiples of ``2**(n_levels-1)`` so that every strip's pyramid is a window of the global
-    pyramid, and the halo is the reach of the coarsest level's 15x15 kernel: ``7 * 2**(n_levels-1)`` rows."""
+    ``n_levels`` = pyramid levels of the bank (SPEC.md §2; 2 for the default 4-scale bank), ``ksize`` its kernel size
+    (default: the largest one the ABI takes, i.e. the most rows). Strip and ownership boundaries are multiples of
+    ``2**(n_levels-1)`` so that every strip's pyramid is a window of the global pyramid, and the halo is the reach of
+    the coarsest level's kernel: ``halo_rows(n_levels, ksize)`` rows."""
     align = 1 << (n_levels - 1)
-    halo = 7 * align
+    halo = halo_rows(n_levels, ksize)
     r0 = (height * rank) // world // align * align
     r1 = height if rank == world - 1 else (height * (rank + 1)) // world // align * align
     return r0, r1, max(0, r0 - halo), min(height, r1 + halo)
@@ -258,7 +265,8 @@ class Segmenter:
     """Reusable plan: bank on device + cached workspaces. ``__call__`` is the slot."""
 
     def __init__(self, n_scales=4, n_orient=6, k=8, n_iter=10, ksize=13, f_max=0.4,
-                 ratio=math.sqrt(2.0), bandwidth=1.0, connectivity=False, device="cuda:0", ops=None):
+                 ratio=math.sqrt(2.0), bandwidth=1.0, connectivity=False, device="cuda:0", ops=None,
+                 slab_candidates=1):
         if not (1 <= k <= _lib.K_MAX):
             raise ValueError(f"k must be in 1..{_lib.K_MAX}")
         if n_iter < 1:
@@ -268,6 +276,10 @@ class Segmenter:
         self.connectivity = bool(connectivity)     # SPEC.md §7 post-pass
         self.bank = make_bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
         self.ops = ops if ops is not None else HipOps(self.bank, device)
+        # feature-slab allocations to time at first use of a large workspace shape (see _place_slab). 1 = take the first
+        # one (the library default: no extra memory, no host synchronisation, graph-capturable); bench.py asks for 2.
+        self.slab_candidates = int(os.environ.get("GCS_SLAB_CANDIDATES", slab_candidates))
+        self.slab_placement_ms = None
         self._ws = {}
         self._host = {}
 
@@ -281,25 +293,36 @@ class Segmenter:
                       partials=self.ops.partial_slab(g, h, w, self.k),
                       cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
             self._place_slab(ws, g, h, w, n_sets)
-            self._ws = {key: ws}          # keep one shape resident
+            # keep the two most recent shapes resident (a data set alternating landscape and portrait batches would
+            # otherwise rebuild - and re-place - its workspace on every switch)
+            if len(self._ws) >= 2:
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = ws
         return ws
 
     def _place_slab(self, ws, g, h, w, n_sets):
-        """Pick the feature-slab allocation the Lloyd pass streams fastest (large slabs only).
+        """Optionally pick, among ``slab_candidates`` allocations, the feature slab the Lloyd pass streams fastest.
 
-        Measured on MI355X (tools/slab_placement.py, profiles/r2_notes.md): the SAME pass kernel on the SAME bytes runs
-        6-7 % faster or slower depending on which 0.9 GB allocation holds them (0.169 vs 0.180 ms, stable per allocation
-        for the life of the process). So a few candidate allocations are timed once, with the pass kernel itself on
-        whatever bytes they hold, and the fastest is kept; the others go back to the allocator. GCS_SLAB_CANDIDATES=1
-        switches this off."""
-        if not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20):
-            return
-        n_cand = int(os.environ.get("GCS_SLAB_CANDIDATES", "6"))
-        n_cand = min(n_cand, (24 << 30) // max(1, ws["feats"].numel()))      # at most 24 GB of candidates
-        if n_cand <= 1:
+        Measured on MI355X (tools/slab_placement.py, profiles/r2_notes.md): the SAME pass kernel on the SAME bytes runs up
+        to 6-7 % faster or slower depending on which 0.9 GB allocation holds them (0.169 vs 0.180 ms, stable per allocation
+        for the life of the process; the first large allocation of a process is usually a fast one, which points at how
+        contiguously the driver could back it - translation reach - rather than at the addresses, which show no pattern).
+        With ``slab_candidates`` > 1 that many allocations are timed once with the pass kernel itself and the fastest is
+        kept; the others go back to the allocator. Off by default (1): it costs transient memory, synchronises the host
+        at first use of a shape and puts extra launches into a profile. bench.py asks for 2 and reports their times."""
+        n_cand = self.slab_candidates
+        if not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20) or n_cand <= 1:
             return
         torch = _torch()
-        cands = [ws["feats"]] + [self.ops.feature_slab(g, h, w) for _ in range(n_cand - 1)]
+        n_cand = min(n_cand, (24 << 30) // max(1, ws["feats"].numel()))      # at most 24 GB of candidates
+        cands = [ws["feats"]]
+        for _ in range(n_cand - 1):
+            try:
+                cands.append(self.ops.feature_slab(g, h, w))
+            except torch.OutOfMemoryError:       # a job that fits with one slab must not fail here
+                break
+        if len(cands) < 2:
+            return
         best = [float("inf")] * len(cands)
         with torch.cuda.device(self.ops.device):
             for s in cands:
@@ -317,6 +340,7 @@ class Segmenter:
                             best[i] = min(best[i], e0.elapsed_time(e1))
         keep = min(range(len(cands)), key=lambda i: best[i])
         ws["feats"] = cands[keep]
+        del cands                                          # the rejected slabs return to torch's caching allocator
         self.slab_placement_ms = best                      # diagnostics (bench.py prints it)
 
     def group_size(self, b, h, w, mode):
@@ -389,8 +413,9 @@ class Segmenter:
         align = 1 << (self.bank.n_levels - 1)
         if s0 % align or r0 % align or (r1 % align and r1 != height) or ((s0 + hs) % align and s0 + hs != height):
             raise ValueError(f"strip boundaries must be multiples of {align} rows (pyramid alignment; use shard_rows)")
-        if (r0 - s0 < 7 * align and s0 > 0) or (s0 + hs - r1 < 7 * align and s0 + hs < height):
-            raise ValueError(f"interior strip edges need {7 * align} halo rows (use shard_rows)")
+        halo = halo_rows(self.bank.n_levels, self.bank.ksize)
+        if (r0 - s0 < halo and s0 > 0) or (s0 + hs - r1 < halo and s0 + hs < height):
+            raise ValueError(f"interior strip edges need {halo} halo rows (use shard_rows)")
         ws = self._tail_workspace(b, hs, w, "global")
         self.ops.gabor_features(strip, ws["feats"])
         k, dfeat = self.k, self.bank.n_features
@@ -429,21 +454,21 @@ class Segmenter:
         the strip runs through ``segment_rows_sharded_device``.
 
         ``owned``: (B, r1-r0, W, 3) uint8 device tensor = rows [r0, r1) of B images of ``height`` rows, with
-        (r0, r1) = ``shard_rows(height, world, rank, n_levels)[:2]``. Every rank must own at least the halo
-        (``7 * 2**(n_levels-1)`` rows), so that a halo comes from ONE neighbour. Returns the (B, r1-r0, W) int32 labels."""
+        (r0, r1) = ``shard_rows(height, world, rank, n_levels, ksize)[:2]``. Every rank must own at least the halo
+        (``halo_rows(n_levels, ksize)`` rows), so that a halo comes from ONE neighbour. Returns the (B, r1-r0, W) int32 labels."""
         torch = _torch()
         import torch.distributed as td
         if not (td.is_available() and td.is_initialized()):
             raise RuntimeError("segment_owned_rows_device needs torch.distributed (one rank per row strip)")
         world, rank = td.get_world_size(dist_group), td.get_rank(dist_group)
-        nl = self.bank.n_levels
-        r0, r1, s0, s1 = shard_rows(height, world, rank, nl)
+        nl, ks = self.bank.n_levels, self.bank.ksize
+        r0, r1, s0, s1 = shard_rows(height, world, rank, nl, ks)
         owned = owned.contiguous()
         b, ho, w, _ = owned.shape
         if ho != r1 - r0:
             raise ValueError(f"rank {rank} owns rows [{r0}, {r1}) of {height}: got {ho} rows")
-        halo = 7 << (nl - 1)
-        bounds = [shard_rows(height, world, r, nl) for r in range(world)]
+        halo = halo_rows(nl, ks)
+        bounds = [shard_rows(height, world, r, nl, ks) for r in range(world)]
         if world > 1 and min(x[1] - x[0] for x in bounds) < halo:
             raise ValueError(f"every rank must own at least {halo} rows for a single-hop halo exchange")
         up, down = rank - 1, rank + 1

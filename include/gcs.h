@@ -34,13 +34,17 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 13
+#define GCS_ABI_VERSION 14
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
 #define GCS_SCALES_MAX 8  /* octave pyramid of at most 4 levels: scales 2L, 2L+1 run on level L (SPEC.md §2) */
 
 int gcs_abi_version(void);
+/* Compute units of the current HIP device (hipDeviceProp_t::multiProcessorCount): the persistent Gabor grid is sized from it;
+ * the Lloyd pass geometry (gcs_kmeans_parts_per_image: a pure host function, so that buffers can be sized without a device)
+ * is tuned for the 256 CUs of an MI355X in SPX mode and merely less efficient elsewhere. */
+int gcs_device_cu_count(void);
 const char *gcs_last_error(void);
 
 /* The bank is described by (n_scales, n_orient): F = n_scales * n_orient filters, f = s * n_orient + o,
@@ -137,8 +141,12 @@ int gcs_labels_raster_u8(const uint8_t *labels_dev, int B, int H, int W, uint8_t
                          gcs_stream_t stream);
 
 /* Test hook: counts in *bad_dev (uint32, device) the 4096-value chunks of [0, n_max] on which the kernels' 7-instruction
- * exact integer square root (SPEC.md §3: n <= 2 * 32642^2) is wrong. Expected 0. */
+ * exact integer square root and its biased form in the epilogue (SPEC.md §3: n <= 2 * 32767^2 < 2^31, guaranteed by the
+ * tap-sum bound of gcs_bank_pack) is wrong. Expected 0. */
 int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_t stream);
+/* Test hook (host only): working workgroups per image of the deep-bank Lloyd pass for a batch shape; B * H * W / that
+ * many pixels per workgroup must stay below the int32 accumulator bound (262 144 pixels). 0 for a bad shape. */
+int gcs_selftest_native_parts(int B, int H, int W);
 
 /* ---- boundary scoring of one image -------------------------------------- */
 
@@ -174,7 +182,8 @@ int gcs_region_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int 
                       uint32_t *perim_dev, gcs_stream_t stream);
 
 /* Batched form (same ragged truth stack as gcs_boundary_counts_batch): first_dev int32 [B+1] = index of each image's first
- * annotator map (first[B] = T), max_annotators = the largest per-image count. hist_dev uint32 [T][n_segments][n_truth_labels],
+ * annotator map (first[B] = T), max_annotators = the largest per-image count (it sizes the
+ * workgroup-private tables; an image that brings more annotators than stated falls back to global atomics, still exact). hist_dev uint32 [T][n_segments][n_truth_labels],
  * area_dev / perim_dev uint32 [B][n_segments]. One launch for the whole batch. */
 int gcs_region_counts_batch(const int32_t *labels_dev, const uint16_t *truth_dev, const int32_t *first_dev, int B, int T,
                             int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist_dev,

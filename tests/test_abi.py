@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 13
+    assert lib.gcs_abi_version() == 14
 
 
 def test_no_torch_types_in_the_abi():
@@ -165,3 +165,18 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "spec_oracle" not in src and "c_oracle" not in src, f
+
+
+def test_native_pass_never_gives_a_workgroup_more_pixels_than_its_int32_accumulators_hold(lib):
+    """the deep-bank pass lets only 512 / B workgroups per image work; its per-wave int32 MFMA accumulators are
+    flushed at the end of the pass and hold at most 524 288 pixels of one label per workgroup. The launcher now raises the
+    working workgroups so that a workgroup owns at most 262 144 pixels (test hook: gcs_selftest_native_parts)."""
+    for b, h, w in [(64, 321, 481), (64, 2048, 2048), (128, 2048, 2048), (32, 4096, 4096), (512, 724, 724), (1, 8192, 8192),
+                    (4096, 321, 481), (1, 321, 481)]:
+        eff = lib.gcs_selftest_native_parts(b, h, w)
+        px = -(-h // 8) * -(-w // 8) * 64
+        assert eff >= 1 and px / eff <= 262144 + 256, (b, h, w, eff)
+        assert eff <= lib.gcs_kmeans_parts_per_image(b, h, w)
+    assert lib.gcs_selftest_native_parts(64, 321, 481) == 8            # the measured configuration is unchanged: 512 workgroups
+    assert lib.gcs_selftest_native_parts(64, 2048, 2048) == 16         # was 8: 524 288 pixels per workgroup = 2^31 in one accumulator
+    assert lib.gcs_selftest_native_parts(0, 8, 8) == 0

@@ -48,7 +48,8 @@ def _strip_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
     from gabor_color_image_segmentation_amd import Segmenter, make_bank, shard_rows
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     imgs = synthetic_batch(b, height, width, seed=13)
-    r0, r1, s0, s1 = shard_rows(height, world, rank)
+    # the halo of the bank's own kernel (13x13 on two levels: 12 rows), not the 15x15 frame's 14
+    r0, r1, s0, s1 = shard_rows(height, world, rank, 2, 13)
     strip = torch.from_numpy(np.ascontiguousarray(imgs[:, s0:s1]))
     if use_gpu:
         seg = Segmenter(k=k, n_iter=n_iter, device="cuda:0")
@@ -63,7 +64,8 @@ def _strip_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_image_equals_unsharded_oracle(tmp_path, world):
-    """BASELINE config 5 in miniature: one image split into row strips with 7-row halos."""
+    """BASELINE config 5 in miniature: one image split into row strips with the halo the bank's kernel needs (6 rows per
+    pyramid level = 12 rows: `halo_rows(2, 13)`; `shard_rows` without a kernel size ships the 15x15 frame's 14)."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so
     port = 31500 + (os.getpid() % 2000) + world
