@@ -156,8 +156,26 @@ class TimedOps:
             return self._ops.assign_accumulate(*a, **kw)
         return self._timed("assign", self._ops.assign_accumulate, *a, **kw)
 
+    # multi-rank update = reduce -> all-reduce -> finalize: one event at the start of `reduce`, one after `finalize`, for the
+    # passes that are sampled anyway (the all-reduce in between goes through torch.distributed, not through these ops)
+    def reduce(self, *a, **kw):
+        self._trio = None
+        if self.enabled and self._n_pass % self.PASS_STRIDE == 4:
+            self._trio = self._torch.cuda.Event(enable_timing=True)
+            self._trio.record()
+        return self._ops.reduce(*a, **kw)
+
+    def finalize(self, *a, **kw):
+        r = self._ops.finalize(*a, **kw)
+        if getattr(self, "_trio", None) is not None:
+            e = self._torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.setdefault("update_trio", []).append((self._trio, e))
+            self._trio = None
+        return r
+
     def mean_ms(self, key):
-        ev = self.events[key]
+        ev = self.events.get(key, [])
         if not ev:
             return float("nan"), 0
         return sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev)), len(ev)
@@ -210,7 +228,9 @@ def main():
     imgs_np = synthetic_shard(rank * B, B, H, W, seed=0)      # this rank's shard of the global batch
     imgs = torch.from_numpy(imgs_np).to(dev)
 
-    seg = Segmenter(k=args.k, n_iter=args.n_iter, device=dev)
+    # two candidate feature-slab allocations are timed once, outside every timed region (Segmenter._place_slab; library
+    # default: one); their pass times are reported as slab_placement_ms
+    seg = Segmenter(k=args.k, n_iter=args.n_iter, device=dev, slab_candidates=2)
     tops = TimedOps(seg.ops, torch)
     seg.ops = tops
     out = torch.empty((B, H, W), dtype=torch.int32, device=dev)
@@ -222,6 +242,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    rank_dt = []
 
     def timed(mode, steps, warmup, events):
         for _ in range(warmup):
@@ -236,9 +258,11 @@ def main():
         dt = time.perf_counter() - t0
         tops.enabled = False
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = dt
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)            # every rank's time; the job's time is the slowest rank's
+            rank_dt[:] = [float(x) for x in t.tolist()]
+            dt = max(rank_dt)
         return dt
 
     # Device spin-up (not a bench step, outside every timed region): the GPU leaves its idle clock state only after
@@ -251,6 +275,7 @@ def main():
     dt = timed(args.mode, args.steps, args.warmup, events=not args.no_events)
     total_px = world * B * H * W
     value = total_px * args.steps / dt / 1e6
+    slab_ms = list(seg.slab_placement_ms or [])     # of the timed workspace (later workspaces place their own slabs)
 
     # per-kernel device time from the events recorded inside the timed region (rank 0's GPU)
     bank = seg.bank
@@ -265,7 +290,7 @@ def main():
     lv = [(3 * min(2, bank.n_scales - 2 * L) * bank.n_orient, 4 ** L) for L in range(bank.n_levels)]
     feat_b = 2 * sum(d / q for d, q in lv)
     g_bytes = (3 + feat_b) * px                      # u8 RGB in + u16 pyramid features out
-    a_bytes = (feat_b + 1 / args.n_iter) * px        # per Lloyd pass: u16 pyramid features in; the u8 labels are stored by the last pass only
+    a_bytes = (feat_b + 4 / args.n_iter) * px        # per Lloyd pass: u16 pyramid features in; the int32 raster label map is stored by the last pass only
     g_ops = sum(2 * bank.ksize ** 2 * (4 * d // 3) * 3 * px / q for d, q in lv)   # int8 MACs x2: 2 digits x {re,im} x F_L rows
     kernels = {
         "gabor_mfma_kernel": dict(launches=g_n, launches_per_step=1, avg_ms=round(g_ms, 4), alg_bytes=int(g_bytes),
@@ -277,8 +302,7 @@ def main():
         "kmeans_pass_mfma_kernel": dict(launches=a_n, launches_per_step=args.n_iter, avg_ms=round(a_ms, 4),
                                      alg_bytes=int(a_bytes), unfused_def_bytes=(2 * D + 1) * px,
                                      gbs=round(a_bytes / a_ms / 1e6, 1),
-                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                     unfused_def_gbs=round((2 * D + 1) * px / a_ms / 1e6, 1)),
+                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4)),
     }
     if g_ms >= a_ms * args.n_iter:    # dominant = larger share of the step (`launches` = launches bracketed by events)
         kg = kernels["gabor_mfma_kernel"]
@@ -291,10 +315,9 @@ def main():
         ka = kernels["kmeans_pass_mfma_kernel"]
         roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ka["hbm_frac"], traffic=None,
-                        alg_bytes_def="pyramid-resident: 2*sum_L D_L/4^L B/px read by every pass + 1 B/px of labels stored by "
-                                      "the last one = 90.1 B/px per launch for the 4x6 bank, n_iter 10; the un-fused (2D+1) "
-                                      "= 145 B/px definition gives unfused_def_gbs",
-                        unfused_def_gbs=ka["unfused_def_gbs"])
+                        alg_bytes_def="pyramid-resident: 2*sum_L D_L/4^L B/px read by every pass + the label map stored by the "
+                                      "last one (4 B/px int32 / n_iter) = 90.4 B/px per launch for the 4x6 bank, n_iter 10 "
+                                      "(SURVEY.md §8d's un-fused 2D+1 = 145 B/px describes work this pass no longer does)")
 
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
     # command (tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no profile matches.
@@ -331,6 +354,15 @@ def main():
             for _ in range(4):
                 seg.segment_batch(imgs_np, mode=args.mode, **kw)
             extra[key] = round(px * 4 / (time.perf_counter() - t0) / 1e6, 1)
+        # the same slot fed from a loader: segment_stream overlaps batch n+1's staging / upload and batch n-1's download
+        # with batch n's compute (three streams); 10 consecutive batches, results handed out in order
+        log("pipelined host path (segment_stream)")
+        for key, kw in (("host_stream_mpix_s", {}), ("host_stream_u8_mpix_s", dict(out_dtype=np.uint8))):
+            for _ in seg.segment_stream((imgs_np for _ in range(3)), mode=args.mode, **kw):
+                pass
+            t0 = time.perf_counter()
+            n_b = sum(1 for _ in seg.segment_stream((imgs_np for _ in range(10)), mode=args.mode, **kw))
+            extra[key] = round(px * n_b / (time.perf_counter() - t0) / 1e6, 1)
         log("single-image latency")
         one = imgs_np[0]
         seg(one)
@@ -355,6 +387,25 @@ def main():
         extra["config4_8x8_bank_mpix_s"] = round(px * n4 / (time.perf_counter() - t0) / 1e6, 1)
         del seg4
 
+    if world == 1 and not args.no_other_mode:
+        # BASELINE config 5's tile: ONE 2048 x 2048 x 3 image on one GPU, unsharded (the row-sharded form over N ranks is
+        # tests/test_distributed.py; its cross-rank halo is halo_rows * 2048 * 3 bytes per interior edge and image)
+        log("timing BASELINE config 5 (one 2048x2048 tile, unsharded)")
+        from gabor_color_image_segmentation_amd import halo_rows
+        big = torch.from_numpy(synthetic_shard(0, 1, 2048, 2048, seed=5)).to(dev)
+        out5 = torch.empty((1, 2048, 2048), dtype=torch.int32, device=dev)
+        for _ in range(3):
+            seg.segment_device(big, mode="global", out=out5)
+        torch.cuda.synchronize(dev)
+        n5 = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n5):
+            seg.segment_device(big, mode="global", out=out5)
+        torch.cuda.synchronize(dev)
+        extra["config5_2048_tile_mpix_s"] = round(2048 * 2048 * n5 / (time.perf_counter() - t0) / 1e6, 1)
+        extra["config5_halo_bytes_per_edge"] = halo_rows(bank.n_levels, bank.ksize) * 2048 * 3
+        del big, out5
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ref, cpu = cpu_baseline(B, args.k, args.n_iter, args.mode)
@@ -363,6 +414,25 @@ def main():
             lab = seg.segment_device(imgs, mode=args.mode).to(torch.uint8).cpu().numpy()
             cpu["labels_match_gpu"] = bool(np.array_equal(lab, ref))
             cpu["labels_compared"] = f"all {B} images, {args.mode} codebook, {lab.size} pixels"
+
+    multi = None
+    if world > 1:
+        # Self-diagnosis of an N > 1 run: what carried the collectives, how even the ranks were, what one update (reduce ->
+        # int64 all-reduce of k (D+1) sums -> finalize) cost on rank 0's stream, and the weak-scaling efficiency that cost
+        # predicts from this run's own kernels: a rank's step is the single-rank step plus (n_iter - 1) updates.
+        u_ms, u_n = tops.mean_ms("update_trio")
+        step_ms = dt / args.steps * 1e3
+        local_ms = g_ms + args.n_iter * a_ms                      # Gabor stage + passes, the part that does not grow with N
+        multi = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
+                     rank_ms_per_step=[round(x / args.steps * 1e3, 3) for x in rank_dt],
+                     rank_ms_min=round(min(rank_dt) / args.steps * 1e3, 3), rank_ms_max=round(max(rank_dt) / args.steps * 1e3, 3),
+                     collective_ms_per_pass=None if u_n == 0 else round(u_ms, 4), collective_samples=u_n,
+                     allreduce_bytes=8 * args.k * (D + 1),
+                     predicted_efficiency=None if u_n == 0 else round(local_ms / (local_ms + (args.n_iter - 1) * u_ms), 4),
+                     note="collective_ms_per_pass = HIP-event time from the start of gcs_kmeans_reduce to the end of "
+                          "gcs_kmeans_finalize around the all-reduce (sampled passes, rank 0); predicted_efficiency = "
+                          "t_local / (t_local + (n_iter-1) * collective) with t_local = Gabor stage + n_iter passes of this run; "
+                          "the driver computes the measured efficiency from the per-N values")
 
     if rank == 0:
         line = dict(metric="Mpix/s segmented (Gabor+k-means), 481x321x3 batch", value=round(value, 1),
@@ -376,14 +446,15 @@ def main():
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"
                                 if args.mode == "global" else f"dp{world} (independent images)"),
                     roofline=roofline, cpu_baseline=cpu, kernels=kernels,
-                    slab_placement_ms=[round(x, 4) for x in getattr(seg, "slab_placement_ms", [])],
+                    slab_placement_ms=[round(x, 4) for x in slab_ms],
+                    device_cu_count=int(seg.ops.lib.gcs_device_cu_count()), multi_gpu=multi,
                     # whole job against the HBM roof: Gabor + n_iter passes, pyramid-resident bytes per pixel (and the
                     # un-fused uint16 definition of SURVEY.md §8d beside it), per GPU
-                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * feat_b + 1, 1),
-                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * feat_b + 1) * px * args.steps / dt / 1e9, 1),
-                                    hbm_frac=round(((3 + feat_b) + args.n_iter * feat_b + 1) * px * args.steps / dt / 1e9
+                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * feat_b + 4, 1),
+                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * feat_b + 4) * px * args.steps / dt / 1e9, 1),
+                                    hbm_frac=round(((3 + feat_b) + args.n_iter * feat_b + 4) * px * args.steps / dt / 1e9
                                                    / HBM_PEAK_GBS, 4),
-                                    unfused_def_bytes_per_px=(3 + 2 * D) + args.n_iter * (2 * D + 1)),
+                                    ),
                     **extra)
         print(json.dumps(line))
     if world > 1:

@@ -34,6 +34,7 @@ SIGNATURES = {
     "gcs_kmeans_init": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_features_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_kmeans_assign_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_kmeans_assign_raster": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "gcs_kmeans_reduce": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_finalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gcs_kmeans_reduce_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -65,7 +65,7 @@ extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
 // kernel runs 3 workgroups per CU, so B*parts aims at one full wave of 256*3 workgroups (a
 // second, partly filled wave of workgroups would idle most of the chip). Lower bound: one
 // workgroup's int32 accumulators must not overflow (<= 65536 pixels); upper bound: at least
-// 8 tiles per workgroup to amortise its prologue.
+// 2 tiles per workgroup (its prologue - centroids, key bases, A fragments - costs about as much as one tile).
 #ifndef GCS_KP_SLOTS
 #define GCS_KP_SLOTS 768
 #endif
@@ -74,7 +74,9 @@ extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
     if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
     const size_t px = (size_t)lo.ntiles * KP_TP;
     const size_t need = (px + 65535) / 65536;
-    size_t most = px / KP_TP / 8;
+    // small batches (B * parts would leave most of the 768 slots empty): down to 2 tiles per workgroup - one image then
+    // runs on 313 workgroups instead of 78 and a pass takes a third of the time (it is latency-bound: 14 MB per image)
+    size_t most = px / KP_TP / 2;
     if (most < 1) most = 1;
     size_t want = (GCS_KP_SLOTS + (size_t)B - 1) / (size_t)B;
     if (want > most) want = most;

@@ -774,11 +774,18 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         m += mtiles(lo.FL[L]);
     }
     const int mtmax = ksize <= 13 ? GCS_GABOR_MTMAX : 2;     // A operand: MT x KS x 4 VGPRs (84 for 3 x 7, 64 for 2 x 8)
+    // A call so small that the tiles of ALL its levels fit the resident slots at once (one to four BSD images) also takes
+    // the fused list: level 1's tiles then run beside level 0's instead of in a launch of their own behind them (one image:
+    // the two launches take 19 us each, one after the other; the slot is called once per image, script.py:22-30).
+    long long tiles_all = 0;
+    for (int L = 0; L < lo.n_levels; ++L)
+        tiles_all += (long long)B * ((ws.WL[L] + G_TW - 1) / G_TW) * ((ws.HL[L] + G_TH - 1) / G_TH);
+    const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
     for (int L0 = 0; L0 < lo.n_levels;) {
         int L1 = L0 + 1;
         // fused lists pay ~2 % for level fields that are no longer launch constants and win the small levels' ramp and
         // tail back: a gain from three levels on (8x8 bank: 0.90 -> 0.80 ms), a small loss for two (0.552 -> 0.557 ms)
-        if (lo.n_levels > 2)
+        if (lo.n_levels > 2 || fuse_small)
             while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
         const int FLg = lo.FL[L0], MT = mtiles(FLg);
         if (L0 == 0 && L1 > 1)                       // this launch reads planes the side stream is still writing

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                                           : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
-    int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials) {
+    int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials,
+    void *__restrict__ raster, int raster_u8) {
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
     constexpr int NTHR = 64 * WAVES;                         // threads per workgroup
     constexpr int NT_OWN = WAVES == 8 ? (KP_NT + 1) / 2 : KP_NT;   // update plane tiles a wave accumulates
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 
     // either output may be absent (host contract): labels == NULL on the passes whose assignment nobody reads (every
     // pass but the last), partials == NULL on the last pass, whose sums nobody reads (no update phase, no fold)
-    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;
+    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;    // (raster: see the assign phase)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = tid >> 6;                                // 0 .. WAVES-1
     const int wave = wid & 3;                                // the block of the tile this wave works on
@@ -548,6 +549,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
                 if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
+                // the label map itself, raster order [B][H][W] (gcs_kmeans_assign_raster: the last pass; no separate
+                // slab -> raster kernel): eight lanes cover one row of the block, 32 (int32) or 8 (uint8) contiguous bytes
+                if (raster && valid) {
+                    const size_t o = ((size_t)(per_image ? b : tile / ntiles) * lo.H + y) * lo.W + x;
+                    if (raster_u8) static_cast<uint8_t *>(raster)[o] = (uint8_t)bj;
+                    else static_cast<int32_t *>(raster)[o] = bj;
+                }
             }
         }
         if (WAVES == 8 && do_acc) __syncthreads();             // the block's labels come from two waves
@@ -669,7 +677,7 @@ template <int NL, int NT, int NST, int MINB>
 __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels,
-    uint64_t *__restrict__ partials) {
+    uint64_t *__restrict__ partials, void *__restrict__ raster, int raster_u8) {
     constexpr int TILE_B = (NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END) + 512;   // + room for the over-reads of unused columns
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[TILE_B];
     __shared__ __attribute__((aligned(16))) int2 s_part[4][NL - 1][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
@@ -903,6 +911,11 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
                 if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
+                if (raster && valid) {                        // raster label map (see kmeans_pass_mfma_kernel)
+                    const size_t o = ((size_t)(per_image ? b : tile / ntiles) * lo.H + y) * lo.W + x;
+                    if (raster_u8) static_cast<uint8_t *>(raster)[o] = (uint8_t)bj;
+                    else static_cast<int32_t *>(raster)[o] = bj;
+                }
             }
         }
         // -------- update (the block's labels were written by this wave: no barrier). Operand loads of a level go out together.
@@ -1095,10 +1108,14 @@ extern "C" int gcs_selftest_native_parts(int B, int H, int W) {
     return native_parts_eff(B, (int)gcs_kmeans_parts_per_image(B, H, W), (long long)lo.ntiles * KP_TP);
 }
 
-extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
-                                            int n_scales, int n_orient, int k, int n_sets, int row_lo, int row_hi,
-                                            int reverse, uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
-    if (!feats || !cent || (!labels && !partials))
+extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream);
+extern "C" int gcs_labels_raster_u8(const uint8_t *labels, int B, int H, int W, uint8_t *out, gcs_stream_t stream);
+
+// One Lloyd pass, whatever it emits: label slab, partial sums, raster label map (any subset, not none).
+static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int n_scales, int n_orient, int k,
+                      int n_sets, int row_lo, int row_hi, int reverse, uint8_t *labels, uint64_t *partials, void *raster,
+                      int raster_u8, gcs_stream_t stream) {
+    if (!feats || !cent || (!labels && !partials && !raster))
         return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer (labels and partials may not both be NULL)");
     LAYOUT_OR_FAIL(lo, "gcs_kmeans_assign_accumulate");
     if (row_lo < 0 || row_hi > H || row_lo >= row_hi)
@@ -1115,7 +1132,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 #define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
-                       reverse ? 1 : 0, row_lo, row_hi, labels, partials)
+                       reverse ? 1 : 0, row_lo, row_hi, labels, partials, raster, raster_u8)
 #define GCS_KP_LAUNCH(KT_, NST_, DS_) GCS_KP_LAUNCHW(KT_, NST_, DS_, 4)
         const int nchunk = lo.tile_bytes / 16;
         const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
@@ -1141,7 +1158,7 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
     hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
-                       reverse ? 1 : 0, row_lo, row_hi, labels, partials)
+                       reverse ? 1 : 0, row_lo, row_hi, labels, partials, raster, raster_u8)
                 if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
                 else if (lo.n_levels == 3) GCS_NV_LAUNCH(3);
                 else GCS_NV_LAUNCH(4);
@@ -1161,15 +1178,39 @@ extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_
         GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
         return GCS_OK;
     }
+    if (raster && !labels)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_raster: feature vectors of 208 or more planes need the scratch label slab");
+    int rc = GCS_EINVAL;
     switch (k) { // generic VALU pass for wider feature vectors
 #define GCS_CASE(KK) \
     case KK:         \
-        return launch_assign<KK>(feats, cent, B, lo, n_sets, row_lo, row_hi, labels, partials, stream);
+        rc = launch_assign<KK>(feats, cent, B, lo, n_sets, row_lo, row_hi, labels, partials, stream); \
+        break;
         GCS_CASE(1) GCS_CASE(2) GCS_CASE(3) GCS_CASE(4) GCS_CASE(5) GCS_CASE(6) GCS_CASE(7) GCS_CASE(8)
         GCS_CASE(9) GCS_CASE(10) GCS_CASE(11) GCS_CASE(12) GCS_CASE(13) GCS_CASE(14) GCS_CASE(15) GCS_CASE(16)
 #undef GCS_CASE
     }
-    return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: unreachable");
+    if (rc != GCS_OK || !raster) return rc;
+    // the generic pass writes the slab only: one more launch turns it into the raster map
+    return raster_u8 ? gcs_labels_raster_u8(labels, B, H, W, static_cast<uint8_t *>(raster), stream)
+                     : gcs_labels_widen(labels, B, H, W, static_cast<int32_t *>(raster), stream);
+}
+
+extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
+                                            int n_scales, int n_orient, int k, int n_sets, int row_lo, int row_hi,
+                                            int reverse, uint8_t *labels, uint64_t *partials, gcs_stream_t stream) {
+    if (!labels && !partials)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: NULL pointer (labels and partials may not both be NULL)");
+    return lloyd_pass(feats, cent, B, H, W, n_scales, n_orient, k, n_sets, row_lo, row_hi, reverse, labels, partials, nullptr, 0,
+                      stream);
+}
+
+extern "C" int gcs_kmeans_assign_raster(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int n_scales,
+                                        int n_orient, int k, int n_sets, int reverse, void *out, int out_u8,
+                                        uint8_t *scratch_labels, gcs_stream_t stream) {
+    if (!out) return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_raster: NULL pointer");
+    return lloyd_pass(feats, cent, B, H, W, n_scales, n_orient, k, n_sets, 0, H, reverse, scratch_labels, nullptr, out,
+                      out_u8 ? 1 : 0, stream);
 }
 
 // sums[set][e] = sum over the set's rows of element e (layout: partial_index in common.h). Integer sums: any order gives

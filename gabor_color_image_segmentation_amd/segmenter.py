@@ -23,6 +23,9 @@ from .bank import GaborBank, make_bank
 # Measurement switch: GCS_NO_REVERSE=1 sweeps every Lloyd pass in the same direction (results identical).
 _NO_REVERSE = bool(os.environ.get("GCS_NO_REVERSE"))
 _SLAB_BUDGET = 16 << 30    # feature-slab bytes per group; measured: one big launch beats cache-sized groups
+# host calls up to this many pixels replay a captured HIP graph of the whole step (GCS_NO_GRAPH=1: launch eagerly)
+_GRAPH_MAX_PIXELS = 1 << 20
+_NO_GRAPH = bool(os.environ.get("GCS_NO_GRAPH"))
 
 
 def _torch():
@@ -128,6 +131,17 @@ class HipOps:
             "gcs_kmeans_assign_accumulate")
 
     @_on_device
+    def assign_raster(self, feats, cent, b, h, w, k, n_sets, out, scratch_labels=None, reverse=False):
+        """The last Lloyd pass with the label map written in raster order: ``out`` (B,H,W) int32 or uint8 device tensor."""
+        torch = self.torch
+        if out.dtype not in (torch.int32, torch.uint8) or tuple(out.shape) != (b, h, w) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (B,H,W) int32 or uint8 tensor")
+        _lib.check(self.lib.gcs_kmeans_assign_raster(
+            feats.data_ptr(), cent.data_ptr(), b, h, w, *self._bk, k, n_sets, 1 if reverse else 0, out.data_ptr(),
+            1 if out.dtype == torch.uint8 else 0, None if scratch_labels is None else scratch_labels.data_ptr(),
+            self._stream()), "gcs_kmeans_assign_raster")
+
+    @_on_device
     def features_gather(self, feats, b, h, w, byx):
         """byx: (n,3) int32 device tensor of (image, row, col); image < 0 -> zero row. -> (n,D) int16."""
         n = byx.shape[0]
@@ -193,7 +207,7 @@ def _collective(fn, t, **kw):
 
 
 def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None,
-          rows=None, init=None, force_collectives=False):
+          rows=None, init=None, force_collectives=False, raster=None):
     """SPEC.md §4 schedule on one feature slab. ``mode``: 'per_image' or 'global'.
 
     In 'global' mode with torch.distributed initialised, the init centroids come from
@@ -203,6 +217,8 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
     excluded); ``init(cent)``: custom centroid initialisation (row-sharded images).
     ``force_collectives``: take the multi-rank branch (reduce, all-reduce, finalize) even in a one-rank
     group, so that a single GPU can exercise the RCCL path end to end (tests).
+    ``raster``: (B,H,W) int32 / uint8 device tensor: the last pass writes the label map there itself (whole images only,
+    ops that have ``assign_raster``) instead of filling the label slab for a separate raster kernel.
     """
     n_sets = b if mode == "per_image" else 1
     dist = None
@@ -224,8 +240,12 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
         # pass runs back to front because the Gabor stage, which has just written the slab, finished at its end
         # only the last pass's labels are read, and its sums are not: either output of the kernel is optional
         last = t == n_iter - 1
+        rev = not (t & 1) and not _NO_REVERSE
+        if last and raster is not None:
+            ops.assign_raster(feats, cent, b, h, w, k, n_sets, raster, scratch_labels=labels, reverse=rev)
+            break
         ops.assign_accumulate(feats, cent, b, h, w, k, n_sets, labels if last else None, None if last else partials, rows,
-                              reverse=not (t & 1) and not _NO_REVERSE)
+                              reverse=rev)
         if not last:
             if dist is None:
                 ops.reduce_finalize(partials, b, h, w, k, n_sets, sums, cent)
@@ -282,6 +302,7 @@ class Segmenter:
         self.slab_placement_ms = None
         self._ws = {}
         self._host = {}
+        self._graphs = {}
 
     # ---- workspaces
     def _workspace(self, g, h, w, mode):
@@ -378,9 +399,12 @@ class Segmenter:
                 n = min(g, b - g0)
                 ws = self._workspace(n, h, w, mode) if n == g else self._tail_workspace(n, h, w, mode)
                 self.ops.gabor_features(imgs[g0:g0 + n], ws["feats"])
+                direct = hasattr(self.ops, "assign_raster")      # the last pass writes the raster map itself
                 lloyd(self.ops, ws["feats"], n, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
-                      ws["cent"], ws["sums"], dist_group, force_collectives=self.force_collectives)
-                self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
+                      ws["cent"], ws["sums"], dist_group, force_collectives=self.force_collectives,
+                      raster=out[g0:g0 + n] if direct else None)
+                if not direct:
+                    self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
             if self.connectivity:
                 regions = torch.empty_like(out)
                 self.ops.connected_regions(out, regions)
@@ -535,6 +559,8 @@ class Segmenter:
             return self.segment_device(dev, mode).cpu().numpy().astype(out_dtype, copy=False)
 
         ops, dev = self.ops, self.ops.device
+        if b * h * w <= _GRAPH_MAX_PIXELS and not _NO_GRAPH:
+            return self._segment_small(imgs, mode, out_dtype)
         st = self._host_state(b, h, w)
         ws = self._workspace(b, h, w, mode)
         per_img = ops.lib.gcs_feature_slab_bytes(1, h, w, self.bank.n_scales, self.bank.n_orient)
@@ -552,19 +578,140 @@ class Segmenter:
                     st["ev"][i].record(st["copy"])
                 cur.wait_event(st["ev"][i])
                 ops.gabor_features(st["dev_in"][g0:g1], ws["feats"][g0 * per_img:])
+            dev_out = st["dev_out"] if out_dtype == np.uint8 else st["dev_out32"]
             lloyd(ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
-                  ws["cent"], ws["sums"])
+                  ws["cent"], ws["sums"], raster=dev_out)
             # The result is a FRESH pinned host buffer per call, handed to the caller as the base of the returned
             # array (torch's caching host allocator recycles it once the caller drops the array): the device-to-host
             # copy lands directly in caller-owned memory, with no pageable copy and no first-touch page faults.
-            if out_dtype == np.uint8:
-                ops.labels_raster_u8(ws["labels"], b, h, w, st["dev_out"])
-                res = torch.empty((b, h, w), dtype=torch.uint8, pin_memory=True)
-                res.copy_(st["dev_out"], non_blocking=True)
-            else:
-                ops.labels_widen(ws["labels"], b, h, w, st["dev_out32"])
-                res = torch.empty((b, h, w), dtype=torch.int32, pin_memory=True)
-                res.copy_(st["dev_out32"], non_blocking=True)
+            res = torch.empty((b, h, w), dtype=dev_out.dtype, pin_memory=True)
+            res.copy_(dev_out, non_blocking=True)
+            cur.synchronize()
+        return res.numpy()
+
+    def segment_stream(self, batches, mode="per_image", out_dtype=np.int32, depth=2):
+        """Pipelined host API: a generator over the label arrays of an iterable of equally shaped (B,H,W,3) uint8 host
+        batches, in order - ``for labels in seg.segment_stream(loader): ...`` instead of calling ``segment_batch`` per batch
+        (the loop of script.py:22-38 over a data set). Results equal ``segment_batch(batch, mode, out_dtype)``.
+
+        Three streams work on ``depth + 1`` buffer slots: while batch n runs through the Gabor stage and the Lloyd passes,
+        batch n+1 is copied into pinned memory and uploaded and the labels of batch n-1 are downloaded into a fresh pinned
+        array that the caller owns. A result is handed out ``depth`` batches after its input was taken (sooner when the
+        input ends)."""
+        torch = _torch()
+        out_dtype = np.dtype(out_dtype)
+        if out_dtype not in (np.dtype(np.int32), np.dtype(np.uint8)):
+            raise ValueError("out_dtype must be int32 or uint8")
+        if mode not in ("per_image", "global"):
+            raise ValueError("mode must be 'per_image' or 'global'")
+        dist_on = False
+        if mode == "global":
+            import torch.distributed as td
+            dist_on = td.is_available() and td.is_initialized()
+        if not hasattr(self.ops, "lib") or self.connectivity or dist_on or self.force_collectives:
+            for imgs in batches:                                   # no pipeline for post-passes / collectives / stand-ins
+                yield self.segment_batch(imgs, mode, out_dtype)
+            return
+        ops, dev = self.ops, self.ops.device
+        n_slots = max(2, int(depth) + 1)
+        st = None
+        pending = []                                               # (event, pinned result) in input order
+        t_dtype = torch.uint8 if out_dtype == np.uint8 else torch.int32
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            for n, imgs in enumerate(batches):
+                imgs = np.ascontiguousarray(imgs)
+                if imgs.dtype != np.uint8 or imgs.ndim != 4 or imgs.shape[3] != 3:
+                    raise ValueError("every batch must be a (B,H,W,3) uint8 array")
+                b, h, w, _ = imgs.shape
+                if st is None:
+                    if h < 8 or w < 8:
+                        raise ValueError("images must be at least 8x8")
+                    if self.group_size(b, h, w, mode) < b:
+                        raise ValueError("batch too large for one feature slab: use smaller batches")
+                    shape = (b, h, w)
+                    ws = self._workspace(b, h, w, mode)
+                    st = dict(pin_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)],
+                              dev_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)],
+                              dev_out=[torch.empty((b, h, w), dtype=t_dtype, device=dev) for _ in range(n_slots)],
+                              up=torch.cuda.Stream(device=dev), down=torch.cuda.Stream(device=dev),
+                              ev_up=[torch.cuda.Event() for _ in range(n_slots)],
+                              ev_done=[torch.cuda.Event() for _ in range(n_slots)],
+                              ev_down=[torch.cuda.Event() for _ in range(n_slots)])
+                elif (b, h, w) != shape:
+                    raise ValueError(f"batch {n} has shape {(b, h, w)}, the stream was opened with {shape}")
+                i = n % n_slots
+                if n >= n_slots:
+                    st["ev_up"][i].synchronize()                   # the slot's previous upload has left the pinned buffer
+                st["pin_in"][i].copy_(torch.from_numpy(imgs))      # host memcpy, while the device works on earlier batches
+                with torch.cuda.stream(st["up"]):
+                    if n >= n_slots:
+                        st["up"].wait_event(st["ev_done"][i])      # dev_in[i] is no longer being read
+                    st["dev_in"][i].copy_(st["pin_in"][i], non_blocking=True)
+                    st["ev_up"][i].record(st["up"])
+                cur.wait_event(st["ev_up"][i])
+                if n >= n_slots:
+                    cur.wait_event(st["ev_down"][i])               # dev_out[i] has been downloaded
+                ops.gabor_features(st["dev_in"][i], ws["feats"])
+                lloyd(ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
+                      ws["sums"], raster=st["dev_out"][i])
+                st["ev_done"][i].record(cur)
+                res = torch.empty((b, h, w), dtype=t_dtype, pin_memory=True)      # caller-owned pinned result
+                with torch.cuda.stream(st["down"]):
+                    st["down"].wait_event(st["ev_done"][i])
+                    res.copy_(st["dev_out"][i], non_blocking=True)
+                    st["ev_down"][i].record(st["down"])
+                ev = torch.cuda.Event()
+                ev.record(st["down"])
+                pending.append((ev, res))
+                if len(pending) > depth:
+                    ev0, res0 = pending.pop(0)
+                    ev0.synchronize()
+                    yield res0.numpy()
+            for ev0, res0 in pending:
+                ev0.synchronize()
+                yield res0.numpy()
+            if st is not None:
+                cur.wait_stream(st["up"])
+                cur.wait_stream(st["down"])
+
+    def _segment_small(self, imgs, mode, out_dtype):
+        """One image (or a small batch): the slot as script.py:22-30 calls it, once per image. A step is ~25 launches of
+        kernels that take microseconds each, so the host's launch calls, not the device, set the latency: the whole step
+        (Gabor stage, n_iter Lloyd passes, label raster) is captured ONCE per shape as a HIP graph on static buffers and
+        replayed per call - upload, one graph launch, download."""
+        torch = _torch()
+        b, h, w, _ = imgs.shape
+        dev = self.ops.device
+        key = (b, h, w, mode, out_dtype.str)
+        ent = self._graphs.get(key)
+        with torch.cuda.device(dev):
+            if ent is None:
+                ws = self._tail_workspace(b, h, w, mode)
+                dev_in = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)
+                dev_out = torch.empty((b, h, w), dtype=torch.uint8 if out_dtype == np.uint8 else torch.int32, device=dev)
+                pin_in = torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True)
+
+                def step():
+                    self.ops.gabor_features(dev_in, ws["feats"])
+                    lloyd(self.ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
+                          ws["sums"], raster=dev_out)
+                dev_in.zero_()
+                step()                                     # eager once: allocates the Gabor scratch outside the capture
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step()
+                ent = dict(graph=graph, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in)
+                if len(self._graphs) >= 4:
+                    self._graphs.pop(next(iter(self._graphs)))
+                self._graphs[key] = ent
+            cur = torch.cuda.current_stream(dev)
+            ent["pin_in"].copy_(torch.from_numpy(imgs))
+            ent["dev_in"].copy_(ent["pin_in"], non_blocking=True)
+            ent["graph"].replay()
+            res = torch.empty((b, h, w), dtype=ent["dev_out"].dtype, pin_memory=True)   # caller-owned pinned result
+            res.copy_(ent["dev_out"], non_blocking=True)
             cur.synchronize()
         return res.numpy()
 

@@ -116,6 +116,15 @@ int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *cent
                                  int row_hi, int reverse, uint8_t *labels_dev, uint64_t *partials_dev,
                                  gcs_stream_t stream);
 
+/* The LAST Lloyd pass in one launch: assignment only (SPEC.md §4; the schedule's last pass has no update) with the label map
+ * written straight in raster order, out_dev [B][H][W] int32 (out_u8 == 0: what metrics.py:43-51 consumes) or uint8
+ * (out_u8 != 0). Same result as gcs_kmeans_assign_accumulate(labels, NULL) followed by gcs_labels_widen /
+ * gcs_labels_raster_u8. scratch_labels_dev: a label slab (gcs_label_slab_bytes) that is needed, and then also filled, only
+ * for feature vectors of 208 or more planes (the generic pass); may be NULL otherwise. Whole images only (no row window). */
+int gcs_kmeans_assign_raster(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B, int H, int W, int n_scales,
+                             int n_orient, int k, int n_sets, int reverse, void *out_dev, int out_u8,
+                             uint8_t *scratch_labels_dev, gcs_stream_t stream);
+
 /* partials -> sums_dev int64 [n_sets][k][D+1] ([..][D] = count). Deterministic slab
  * reduction (no float, no atomics). In global mode the caller all-reduces sums_dev across
  * ranks (RCCL, int64 sum) between this call and gcs_kmeans_finalize. */

@@ -46,7 +46,8 @@ def test_geometry(lib):
     assert lib.gcs_bank_packed_bytes(9, 1) == 0 and lib.gcs_bank_packed_bytes(0, 1) == 0
     p = lib.gcs_kmeans_parts_per_image(64, 321, 481)
     assert p == 12 and tiles * 256 / p <= 65536                # 64 * 12 = 768 workgroups = 256 CUs x 3
-    assert lib.gcs_kmeans_parts_per_image(1, 321, 481) * 8 <= tiles                      # >= 8 tiles per workgroup
+    assert lib.gcs_kmeans_parts_per_image(1, 321, 481) == tiles // 2                     # one image: 2 tiles per workgroup (313 of the 768 slots)
+    assert lib.gcs_kmeans_parts_per_image(8, 321, 481) == 96                             # 8 x 96 = 768
     assert lib.gcs_kmeans_parts_per_image(1, 2048, 2048) * 65536 >= 2048 * 2048
     assert lib.gcs_kmeans_parts_per_image(4096, 321, 481) * 65536 >= tiles * 256
     assert lib.gcs_kmeans_partial_bytes(64, 321, 481, 72, 8) == 64 * p * (-(-8 * 73 // 16) * 16) * 8   # chunks of 16 elements

@@ -220,6 +220,12 @@ def test_bench_two_ranks_as_the_driver_launches_it(tmp_path, built):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and np.isfinite(d["value"]) and d["steps"] == 2
     assert d["config"]["codebook"] == "global" and "all-reduce" in d["config"]["parallelism"]
+    # the N > 1 run diagnoses itself: backend, per-rank times, the cost of one update with its all-reduce
+    m = d["multi_gpu"]
+    assert m["world_size"] == 2 and m["backend"] == "gloo" and len(m["rank_ms_per_step"]) == 2
+    assert m["rank_ms_min"] <= m["rank_ms_max"] and abs(m["rank_ms_max"] - d["ms_per_step"]) < 1e-6
+    assert m["collective_samples"] >= 1 and m["collective_ms_per_pass"] > 0 and m["allreduce_bytes"] == 8 * 8 * 73
+    assert 0 < m["predicted_efficiency"] <= 1
 
 
 def _owned_rows_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):

@@ -81,6 +81,42 @@ def test_segment_single_image_matches_batch(torch_cuda):
         assert np.array_equal(segment(imgs[b], n_iter=3), batch[b])
 
 
+def test_small_host_calls_replay_a_captured_graph_and_equal_the_eager_path(torch_cuda):
+    """segment(img) / small segment_batch calls replay one HIP graph per shape (segmenter._segment_small): different images,
+    both label dtypes, two alternating shapes and both codebook modes give exactly what the eager device path gives."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    seg = Segmenter(n_iter=3)
+    for rnd in range(2):
+        for (b, h, w), seed in (((1, 321, 481), 5), ((1, 481, 321), 6), ((3, 64, 88), 7)):
+            imgs = _synth(b, h, w, seed=seed + 10 * rnd)
+            for mode in ("per_image", "global"):
+                want = seg.segment_device(torch.from_numpy(imgs).cuda(), mode=mode).cpu().numpy()
+                got = seg.segment_batch(imgs, mode=mode)
+                assert got.dtype == np.int32 and np.array_equal(got, want), (rnd, b, h, w, mode)
+            got8 = seg.segment_batch(imgs, out_dtype=np.uint8)
+            assert got8.dtype == np.uint8 and np.array_equal(got8, seg.segment_device(torch.from_numpy(imgs).cuda()).cpu().numpy())
+    assert len(seg._graphs) >= 2                               # the graphs were used (and the cache stays bounded)
+    assert len(seg._graphs) <= 4
+
+
+def test_segment_stream_equals_segment_batch(torch_cuda):
+    """The pipelined host API (three streams, depth + 1 buffer slots): seven batches through segment_stream give, in order,
+    exactly what segment_batch gives for each - both label dtypes, both codebook modes, a depth larger than the input."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    seg = Segmenter(n_iter=3)
+    batches = [_synth(6, 72, 104, seed=30 + i) for i in range(7)]
+    for mode, dt, depth in (("per_image", np.int32, 2), ("global", np.uint8, 1), ("per_image", np.uint8, 9)):
+        want = [seg.segment_batch(x, mode=mode, out_dtype=dt) for x in batches]
+        got = list(seg.segment_stream(iter(batches), mode=mode, out_dtype=dt, depth=depth))
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            assert g.dtype == dt and np.array_equal(g, w_)
+    assert list(seg.segment_stream(iter([]))) == []
+    with pytest.raises(ValueError):
+        list(seg.segment_stream(iter([batches[0], _synth(6, 64, 104, seed=1)])))
+
+
 def test_global_codebook_bit_exact(torch_cuda):
     from gabor_color_image_segmentation_amd import Segmenter
     imgs = _synth(4, 40, 64, seed=8)
@@ -149,8 +185,8 @@ def test_lloyd_pass_with_one_output_only(torch_cuda, ns, no):
 
 
 def test_step_replays_from_a_captured_graph(torch_cuda):
-    """The C ABI's stream contract (include/gcs.h): a whole step, including the side-stream fork / join inside
-    gcs_gabor_features (batch >= 2 Mpix), is captured as a HIP graph; replays on new inputs equal the eager result."""
+    """The C ABI's stream contract (include/gcs.h): a whole step is captured as a HIP graph (gcs_gabor_features keeps a
+    captured call on the capturing stream: no side-stream fork); replays on new inputs equal the eager result."""
     import torch
     from gabor_color_image_segmentation_amd import Segmenter
     b, h, w = 16, 321, 481

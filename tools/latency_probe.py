@@ -1,5 +1,6 @@
 import time, numpy as np, torch, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gabor_color_image_segmentation_amd import Segmenter, segment
 from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
 imgs = synthetic_batch(4, 321, 481, seed=1)
