@@ -14,6 +14,7 @@
 // (gcs_gabor_features forks level 1 of a large two-level batch onto a side stream and joins it back, see there).
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 constexpr int G_TW = 64;            // output tile width  (8 lanes-in-x * 8 shifts)
 constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
@@ -824,7 +825,11 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             }
             const int total_tiles = (int)total_ll;
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
-            const int slots = gcs_cu_count() * 2;
+            int slots = gcs_cu_count() * 2;
+            if (const char *e = getenv("GCS_GABOR_SLOTS")) {      // experiments: a smaller persistent grid (tools/overlap_probe.py)
+                const int v = atoi(e);
+                if (v > 0 && v < slots) slots = v;
+            }
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
