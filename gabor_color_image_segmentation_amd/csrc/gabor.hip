@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
 #ifndef GCS_GABOR_ASMDMA
 #define GCS_GABOR_ASMDMA 1    // LDS-DMA through asm (0: the builtin; A/B builds)
 #endif
+#ifndef GCS_GABOR_L1_FIRST
+#define GCS_GABOR_L1_FIRST 0   // two-level banks: level-1 launch in front of the level-0 launch (A/B builds)
+#endif
 #ifndef GCS_GABOR_MTMAX_
 #define GCS_GABOR_MTMAX_ 3
 #endif
@@ -297,6 +300,7 @@ struct GaborLevels {
 // current pair's chains run.
 constexpr int G_COPY = 3 * G_LROWS * G_LPITCH;      // bytes of one copy of a tile (three channels)
 
+
 template <int MT, int GQ, int KS, int LVL, bool FAST>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, int bx_n, int ntiles,
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler should know it (SGPR address math)
 
     // level of a tile of the list (uniform; a workgroup's tiles only move up the levels). Selected field by field: a
     // dynamically indexed by-value kernel argument would be copied to scratch.
@@ -737,7 +741,10 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         side_lock.unlock();
         return e == hipSuccess ? GCS_OK : gcs_hip_fail(e, "gcs_gabor_features(join)");
     };
-#define GCS_STREAM_OF(L) ((forked && (L) >= 1) ? sd->s : stream)
+    // which level runs on the side stream: level 1 (its launch then fills the tail of level 0's), or - GCS_GABOR_L1_FIRST,
+    // experiment - level 0's PRE-PASS only, with the level-1 launch in front of the level-0 launch on the caller's stream
+    const bool l1_first = forked && GCS_GABOR_L1_FIRST;
+#define GCS_STREAM_OF(L) ((forked && (l1_first ? (L) == 0 : (L) >= 1)) ? sd->s : stream)
 #define GCS_GABOR_CHECK(what)                                    \
     do {                                                         \
         hipError_t e_ = hipGetLastError();                       \
@@ -782,14 +789,14 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     for (int L = 0; L < lo.n_levels; ++L)
         tiles_all += (long long)B * ((ws.WL[L] + G_TW - 1) / G_TW) * ((ws.HL[L] + G_TH - 1) / G_TH);
     const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
-    for (int L0 = 0; L0 < lo.n_levels;) {
-        int L1 = L0 + 1;
+    auto launch_group = [&](int L0, int &L1) -> int {
+        L1 = L0 + 1;
         // fused lists pay ~2 % for level fields that are no longer launch constants and win the small levels' ramp and
         // tail back: a gain from three levels on (8x8 bank: 0.90 -> 0.80 ms), a small loss for two (0.552 -> 0.557 ms)
         if (lo.n_levels > 2 || fuse_small)
             while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
         const int FLg = lo.FL[L0], MT = mtiles(FLg);
-        if (L0 == 0 && L1 > 1)                       // this launch reads planes the side stream is still writing
+        if ((L0 == 0 && L1 > 1) || (l1_first && L0 == 0))    // this launch reads planes the side stream is still writing
             if (int rc = join()) return rc;
         // three row tiles only for single launches of level 0 / 1 (compile-time level): with the level a run-time value the
         // store path of every level is live and a third tile's 28 A registers spill
@@ -832,7 +839,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             }
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, (l1_first ? stream : GCS_STREAM_OF(L0)), G, FLg, 4 * mt0, shift,  \
                        reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
             // single launches of level 0 / level 1 (every bank of at most two levels) compile that level's store path alone
 #define GCS_GABOR_LAUNCH3(MT_, GQ_, KS_, FA_)                                       \
@@ -866,7 +873,15 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
 #undef GCS_GABOR_LAUNCH2
             GCS_GABOR_CHECK("gcs_gabor_features");
         }
-        L0 = L1;
+        return GCS_OK;
+    };
+    if (l1_first) {                                  // two levels: level 1, then (after the join) level 0
+        int e = 0;
+        if (int rc = launch_group(1, e)) return rc;
+        if (int rc = launch_group(0, e)) return rc;
+    } else {
+        for (int L0 = 0, L1 = 0; L0 < lo.n_levels; L0 = L1)
+            if (int rc = launch_group(L0, L1)) return rc;
     }
     if (int rc = join()) return rc;
 #undef GCS_GABOR_CHECK
