@@ -14,7 +14,6 @@
 // (gcs_gabor_features forks level 1 of a large two-level batch onto a side stream and joins it back, see there).
 #include "common.h"
 #include <mutex>
-#include <stdlib.h>
 
 constexpr int G_TW = 64;            // output tile width  (8 lanes-in-x * 8 shifts)
 constexpr int G_TH = 32;            // output tile height (4 waves * 8 rows)
@@ -62,17 +61,10 @@ __device__ __forceinline__ unsigned isqrt31_biased(unsigned n) {
     asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q), "=s"(carry_out) : "v"(bits), "s"(gt));
     return q;
 }
-// a_re^2 + a_im^2 of the packed pair (a_re | a_im << 16), both int16: v_dot2_i32_i16 in its three-address form (the
-// builtin selects the accumulating two-address form, which needs a zeroed destination first)
+// a_re^2 + a_im^2 of the packed pair (a_re | a_im << 16), both int16, by two v_mad_i32_i16 (low halves, then high halves
+// through op_sel): two ordinary-rate instructions where v_dot2_i32_i16 costs about two and a half beside a running MFMA
+// chain (tools/ubench/mfma_beside; profiles/r3_notes.md)
 __device__ __forceinline__ unsigned norm2_i16x2(unsigned p) {
-    unsigned n;
-    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(n) : "v"(p));
-    return n;
-}
-
-// the same squared norm by two v_mad_i32_i16 (low halves, then high halves through op_sel): two ordinary-rate
-// instructions where v_dot2_i32_i16 costs about two and a half beside a running MFMA chain (tools/ubench/mfma_beside)
-__device__ __forceinline__ unsigned norm2_i16x2_mad(unsigned p) {
     unsigned lo, n;
     asm("v_mad_i32_i16 %0, %1, %1, 0" : "=v"(lo) : "v"(p));
     asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[1,1,0,0]" : "=v"(n) : "v"(p), "v"(lo));
@@ -241,21 +233,6 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
 #ifndef GCS_GABOR_WAVES
 #define GCS_GABOR_WAVES 2
 #endif
-#ifndef GCS_GABOR_FAST
-#define GCS_GABOR_FAST 5      // shift-8 epilogue variant, bit mask (see epi_out); 0: every launch takes the general epilogue
-#endif
-#ifndef GCS_GABOR_ABL
-#define GCS_GABOR_ABL 0       // timing ablations (tools/ab.py builds): 1 no stores, 2 trivial epilogue, 4 one MFMA per chain,
-#endif                       // 8 window read once per block, 16 no staging of further tiles. Results are wrong with any bit set.
-#ifndef GCS_GABOR_SLOTBAR
-#define GCS_GABOR_SLOTBAR 0   // scheduling barrier after every MFMA slot (0: one per chain; A/B builds)
-#endif
-#ifndef GCS_GABOR_ASMDMA
-#define GCS_GABOR_ASMDMA 1    // LDS-DMA through asm (0: the builtin; A/B builds)
-#endif
-#ifndef GCS_GABOR_L1_FIRST
-#define GCS_GABOR_L1_FIRST 0   // two-level banks: level-1 launch in front of the level-0 launch (A/B builds)
-#endif
 #ifndef GCS_GABOR_MTMAX_
 #define GCS_GABOR_MTMAX_ 3
 #endif
@@ -350,15 +327,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                 // buffer nobody reads before the barrier at the end of the tile, where vmcnt is drained explicitly.
                 const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t *)(&s_tile[buf][0][0][0][0]) +
                                      16u * (unsigned)(256 * k + 64 * wave);
-#if GCS_GABOR_ASMDMA
                 unsigned m0_saved;             // M0 is reserved by hipcc: hand it back as it was
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(m0_saved) : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(g));
-#else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)(&s_tile[buf][0][0][0][0] + 16 * (256 * k + 64 * wave)), 16, 0, 0);
-                (void)lds;
-#endif
             }
         }
     };
@@ -410,7 +381,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
       }
       if (tile + (int)gridDim.x < total_tiles) {
           lvl_next = level_of(tile + gridDim.x, lvl);
-          if (!(GCS_GABOR_ABL & 16)) stage_tile(tile + gridDim.x, lvl_next, buf ^ 1);
+          stage_tile(tile + gridDim.x, lvl_next, buf ^ 1);
       }
       const int tl = tile - tile0;
       const int b = tl / tiles_per_image, trem = tl % tiles_per_image;
@@ -433,10 +404,6 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         // tap row 2 kk + h (this half-wave's parity)
         auto load_fragment = [&](int kk, int wc, int wtrow, int copy, int qq) -> v4i {
             const int8_t *rp = &s_tile[buf][copy][wc][wtrow + 2 * kk + h][8 * li];
-            if (GCS_GABOR_ABL & 32) {          // timing ablation: fragments made up by four VALU instructions, no LDS read
-                const int a = (int)(size_t)rp;
-                return v4i{a + qq, a ^ 0x55, a + 7, a ^ kk};
-            }
             if (qq == 0) {
                 const v2i lo = *reinterpret_cast<const v2i *>(rp), hi = *reinterpret_cast<const v2i *>(rp + 8);
                 return v4i{lo[0], lo[1], hi[0], hi[1]};
@@ -448,28 +415,17 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         // 2 fp + h of the tile at pixel 2 pp + sx -> its magnitude (FAST: plus 0x4B000000, dropped when the pair is packed).
         auto epi_out = [&](const v16i &ac, int mt, int fp, int sx) -> unsigned {
             const int i = 2 * fp + sx;
-            if constexpr ((GCS_GABOR_ABL & 2) != 0) {
-                return (unsigned)(ac[4 * i] ^ ac[4 * i + 1] ^ ac[4 * i + 2] ^ ac[4 * i + 3]);
-            } else if constexpr (FAST) {
+            if constexpr (FAST) {
                 // a = (256 H + L + bias) >> 8 = H + ((L + bias) >> 8), |a| < 2^15 (gcs_bank_pack bounds sum |tapq|), so
                 // the low 16 bits of H and bytes 1-2 of L + bias add up to a in 16-bit arithmetic: one v_perm packs
-                // (H_re, H_im), one packs and shifts (L_re + bias, L_im), v_pk_add_u16 gives (a_re | a_im << 16), then the
-                // squared norm of the pair and the root. GCS_GABOR_FAST picks the instructions (A/B builds): bit 0 the
-                // v_cmp / v_subb root tail, bit 1 v_dot2 for the norm (else two v_mad_i32_i16), bit 2 the packed front end
-                // (else the general v_mad_i32_i24 / shift / v_mul_i32_i24 front end with only the tail changed).
-                unsigned n;
-                if constexpr ((GCS_GABOR_FAST & 4) != 0) {
-                    const unsigned ph = __builtin_amdgcn_perm((unsigned)ac[4 * i + 3], (unsigned)ac[4 * i + 1], 0x05040100u);
-                    const unsigned pl = __builtin_amdgcn_perm((unsigned)ac[4 * i + 2], (unsigned)(ac[4 * i + 0] + bias_v[mt][fp]), 0x06050201u);
-                    const v2s pa = __builtin_bit_cast(v2s, ph) + __builtin_bit_cast(v2s, pl);
-                    n = (GCS_GABOR_FAST & 2) ? norm2_i16x2(__builtin_bit_cast(unsigned, pa)) : norm2_i16x2_mad(__builtin_bit_cast(unsigned, pa));
-                } else {
-                    const int v_re = __mul24(ac[4 * i + 1], k256) + ac[4 * i + 0] + bias_v[mt][fp];
-                    const int v_im = __mul24(ac[4 * i + 3], k256) + ac[4 * i + 2];
-                    const int a_re = v_re >> 8, a_im = v_im >> 8;
-                    n = (unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im);
-                }
-                return (GCS_GABOR_FAST & 1) ? isqrt31_biased(n) : isqrt31(n) + 0x4B000000u;
+                // (H_re, H_im), one packs and shifts (L_re + bias, L_im), v_pk_add_u16 gives (a_re | a_im << 16), two
+                // v_mad_i32_i16 its squared norm, then the root: 13 VALU instructions per output with packing (round 2: 15
+                // plus 3.5 for the window). Variants measured in profiles/r3_notes.md (v_dot2 for the norm, the general front
+                // end with only the root tail changed).
+                const unsigned ph = __builtin_amdgcn_perm((unsigned)ac[4 * i + 3], (unsigned)ac[4 * i + 1], 0x05040100u);
+                const unsigned pl = __builtin_amdgcn_perm((unsigned)ac[4 * i + 2], (unsigned)(ac[4 * i + 0] + bias_v[mt][fp]), 0x06050201u);
+                const v2s pa = __builtin_bit_cast(v2s, ph) + __builtin_bit_cast(v2s, pl);
+                return isqrt31_biased(norm2_i16x2(__builtin_bit_cast(unsigned, pa)));
             } else {
                 // v = 256*hi + lo (+ bias): v_mad_i32_i24 (|hi| < 2^22); the factor sits in an SGPR the
                 // compiler cannot see through, or it turns the multiply into a left shift (2.3x slower here)
@@ -507,8 +463,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             // compile-time geometry for single-level launches
             const int Lc = LVL >= 0 ? LVL : L, ssh = LVL >= 0 ? 3 - LVL : side_sh, nplc = LVL >= 0 ? (KP_TP >> (2 * (LVL >= 0 ? LVL : 0))) : npl;
             const int oy = y0 + st_trow, ox = x0 + 8 * li;
-            if ((GCS_GABOR_ABL & 1) && oy == -12345) feats[lane] = (unsigned char)(outp[0][0][0] ^ outp[MT - 1][GQ - 1][3]);
-            if (!(GCS_GABOR_ABL & 1) && oy < HL && ox < pitchL) {
+            if (oy < HL && ox < pitchL) {
                 const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
                 const int bx0 = ox >> ssh;
                 // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
@@ -597,9 +552,8 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     // chain of the previous block, whose stores follow it. The scheduling barrier after every slot keeps the
                     // MFMAs evenly spaced and the LDS reads behind the MFMA that frees their registers (hoisted, they need a
                     // second set of fragment registers: 22 spilled VGPRs at MT = 3).
-                    if (!((GCS_GABOR_ABL & 4) && kk > 0))
-                        acc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], win[kk], acc[t & 1], 0, 0, 0);
-                    if (mt == MT - 1 && !(GCS_GABOR_ABL & 8))
+                    acc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[mt][kk], win[kk], acc[t & 1], 0, 0, 0);
+                    if (mt == MT - 1)
                         win[kk] = ws < 3 ? load_fragment(kk, c, trow, (ws + 1) >> 1, (ws + 1) & 1) : load_fragment(kk, cn, trown, 0, 0);
                     if (t > 0) {
                         const int wp = (t - 1) / MT;
@@ -607,7 +561,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     } else if (j > 0) {
                         epi_slice(acc[(NT - 1) & 1], MT - 1, 3, kk);
                     }
-                    if (GCS_GABOR_SLOTBAR || kk == KS - 1) __builtin_amdgcn_sched_barrier(0);
+                    if (kk == KS - 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (t == 0 && j > 0) store_block();
             }
@@ -741,10 +695,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         side_lock.unlock();
         return e == hipSuccess ? GCS_OK : gcs_hip_fail(e, "gcs_gabor_features(join)");
     };
-    // which level runs on the side stream: level 1 (its launch then fills the tail of level 0's), or - GCS_GABOR_L1_FIRST,
-    // experiment - level 0's PRE-PASS only, with the level-1 launch in front of the level-0 launch on the caller's stream
-    const bool l1_first = forked && GCS_GABOR_L1_FIRST;
-#define GCS_STREAM_OF(L) ((forked && (l1_first ? (L) == 0 : (L) >= 1)) ? sd->s : stream)
+#define GCS_STREAM_OF(L) ((forked && (L) >= 1) ? sd->s : stream)
 #define GCS_GABOR_CHECK(what)                                    \
     do {                                                         \
         hipError_t e_ = hipGetLastError();                       \
@@ -796,7 +747,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         if (lo.n_levels > 2 || fuse_small)
             while (L1 < lo.n_levels && lo.FL[L1] == lo.FL[L0]) ++L1;
         const int FLg = lo.FL[L0], MT = mtiles(FLg);
-        if ((L0 == 0 && L1 > 1) || (l1_first && L0 == 0))    // this launch reads planes the side stream is still writing
+        if (L0 == 0 && L1 > 1)                       // this launch reads planes the side stream is still writing
             if (int rc = join()) return rc;
         // three row tiles only for single launches of level 0 / 1 (compile-time level): with the level a run-time value the
         // store path of every level is live and a third tile's 28 A registers spill
@@ -832,14 +783,10 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             }
             const int total_tiles = (int)total_ll;
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
-            int slots = gcs_cu_count() * 2;
-            if (const char *e = getenv("GCS_GABOR_SLOTS")) {      // experiments: a smaller persistent grid (tools/overlap_probe.py)
-                const int v = atoi(e);
-                if (v > 0 && v < slots) slots = v;
-            }
+            const int slots = gcs_cu_count() * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, (l1_first ? stream : GCS_STREAM_OF(L0)), G, FLg, 4 * mt0, shift,  \
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
                        reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
             // single launches of level 0 / level 1 (every bank of at most two levels) compile that level's store path alone
 #define GCS_GABOR_LAUNCH3(MT_, GQ_, KS_, FA_)                                       \
@@ -852,14 +799,14 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
 #define GCS_GABOR_LAUNCH2(MT_, KS_)                                       \
     do {                                                                  \
         if (gq == 1) GCS_GABOR_LAUNCH3(MT_, 1, KS_, false);               \
-        else if (shift == 8 && GCS_GABOR_FAST != 0) GCS_GABOR_LAUNCH3(MT_, 2, KS_, true); \
+        else if (shift == 8) GCS_GABOR_LAUNCH3(MT_, 2, KS_, true);        \
         else GCS_GABOR_LAUNCH3(MT_, 2, KS_, false);                       \
     } while (0)
             // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
             if (ksize <= 13) {
                 if (n == 3) {                    // single launch of level 0 or 1 (mtmax_here)
                     if (gq == 1) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 1, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 1, 7, 1, false); }
-                    else if (shift == 8 && GCS_GABOR_FAST != 0) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, true); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, true); }
+                    else if (shift == 8) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, true); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, true); }
                     else { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, false); }
                 }
                 else if (n == 2) GCS_GABOR_LAUNCH2(2, 7);
@@ -875,14 +822,8 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         }
         return GCS_OK;
     };
-    if (l1_first) {                                  // two levels: level 1, then (after the join) level 0
-        int e = 0;
-        if (int rc = launch_group(1, e)) return rc;
-        if (int rc = launch_group(0, e)) return rc;
-    } else {
-        for (int L0 = 0, L1 = 0; L0 < lo.n_levels; L0 = L1)
-            if (int rc = launch_group(L0, L1)) return rc;
-    }
+    for (int L0 = 0, L1 = 0; L0 < lo.n_levels; L0 = L1)
+        if (int rc = launch_group(L0, L1)) return rc;
     if (int rc = join()) return rc;
 #undef GCS_GABOR_CHECK
 #undef GCS_STREAM_OF
