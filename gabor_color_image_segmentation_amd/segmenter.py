@@ -700,16 +700,23 @@ class Segmenter:
                 step()                                     # eager once: allocates the Gabor scratch outside the capture
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    step()
-                ent = dict(graph=graph, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in)
+                try:
+                    with torch.cuda.graph(graph):
+                        step()
+                except RuntimeError:                       # capture refused (e.g. another capture is open): launch eagerly
+                    graph = None
+                    torch.cuda.synchronize(dev)
+                ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in)
                 if len(self._graphs) >= 4:
                     self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[key] = ent
             cur = torch.cuda.current_stream(dev)
             ent["pin_in"].copy_(torch.from_numpy(imgs))
             ent["dev_in"].copy_(ent["pin_in"], non_blocking=True)
-            ent["graph"].replay()
+            if ent["graph"] is not None:
+                ent["graph"].replay()
+            else:
+                ent["step"]()
             res = torch.empty((b, h, w), dtype=ent["dev_out"].dtype, pin_memory=True)   # caller-owned pinned result
             res.copy_(ent["dev_out"], non_blocking=True)
             cur.synchronize()
