@@ -7,6 +7,9 @@ in the slot, on the packed BSD fixtures (no JPEG / .mat decoding, no /root/refer
 Iterates an explicit sorted id list (script.py:21-22 takes os.listdir order, which is not stable).
 `--gpu-scoring`: the label map never leaves the device; gcs_boundary_counts / gcs_region_counts produce the integer
 tables and the same numbers are printed (evaluate_gpu.all_scores_device).
+`--val`: the data-set form of the same loop on the 24 packed images of the BSD500 val split: batches per image shape through
+the device path, the batched GPU scorer against the packed ground truth of all 500 ids, mean recall / precision / F beside the
+numbers the reference's own metrics class gave for the same label maps (tests/golden/bsd_val_scores.json).
 """
 import os
 import sys
@@ -18,7 +21,36 @@ from gabor_color_image_segmentation_amd import segment                      # no
 from gabor_color_image_segmentation_amd.evaluate import metrics             # noqa: E402  (script.py:14)
 from gabor_color_image_segmentation_amd.groundtruth import load_packed      # noqa: E402  (script.py:13)
 
+def val_split():
+    import json
+    import numpy as np
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_batch_device
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
+    gold = os.path.join(ROOT, "tests", "golden")
+    pack = np.load(os.path.join(gold, "bsd_val_images.npz"))
+    ref = json.load(open(os.path.join(gold, "bsd_val_scores.json")))["per_id"]
+    truth = PackedTruth(os.path.join(gold, "bsd500_truth.npz"))
+    seg = Segmenter()
+    ids = [str(i) for i in pack["ids"]]
+    rows = {}
+    for shape in sorted({pack["img_" + i].shape[:2] for i in ids}):
+        group = [i for i in ids if pack["img_" + i].shape[:2] == shape]
+        labels = seg.segment_device(torch.from_numpy(np.stack([pack["img_" + i] for i in group])).cuda())
+        for i, s in zip(group, all_scores_batch_device(labels, *truth.stack(group))):
+            rows[i] = s
+            print("%-8s Regions: %d Recall: %.4f Precision: %.4f F-measure: %.4f   (reference class: %.4f)"
+                  % (i, s["regions"], s["recall"], s["precision"], s["fmeasure"], ref[i]["v2"]["fmeasure"]))
+    for key in ("recall", "precision", "fmeasure"):
+        print("mean %-9s %.4f   reference class on the same maps: %.4f" % (
+            key, float(np.mean([rows[i][key] for i in ids])), float(np.mean([ref[i]["v2"][key] for i in ids]))))
+
+
 if __name__ == '__main__':
+    if "--val" in sys.argv:
+        val_split()
+        sys.exit(0)
     data = load_packed(os.path.join(ROOT, "tests", "golden", "bsd_inputs.npz"))
     for name in sorted(data):
         img, segments = data[name]                       # script.py:25, :33
