@@ -26,6 +26,22 @@ int gcs_cu_count() {
 }
 extern "C" int gcs_device_cu_count(void) { return gcs_cu_count(); }
 
+// Device -> pinned host memory through the copy engines. hipMemcpyAsync / hipMemcpyDtoHAsync in this direction are served by a
+// blit kernel (__amd_rocclr_copyBuffer in the kernel trace) that fills the chip: for as long as PCIe takes, the kernels of
+// every other stream crawl. The pitched form goes down the runtime's rectangle path, which hands the copy to SDMA
+// (tools/d2h_engine_probe.py: 55 GB/s, no kernel in the trace; profiles/r3_notes.md).
+extern "C" int gcs_download(const void *src_dev, void *dst_host, size_t bytes, gcs_stream_t stream) {
+    if (!bytes) return GCS_OK;
+    if (!src_dev || !dst_host) return gcs_fail(GCS_EINVAL, "gcs_download: NULL pointer");
+    const size_t row = 65536, rows = bytes / row, rest = bytes - rows * row;
+    hipError_t e = hipSuccess;
+    if (rows) e = hipMemcpy2DAsync(dst_host, row, src_dev, row, row, rows, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && rest)
+        e = hipMemcpy2DAsync(static_cast<char *>(dst_host) + rows * row, rest, static_cast<const char *>(src_dev) + rows * row,
+                             rest, rest, 1, hipMemcpyDeviceToHost, stream);
+    return e == hipSuccess ? GCS_OK : gcs_hip_fail(e, "gcs_download(hipMemcpy2DAsync)");
+}
+
 extern "C" int gcs_abi_version(void) { return GCS_ABI_VERSION; }
 extern "C" const char *gcs_last_error(void) { return g_err; }
 

@@ -28,6 +28,8 @@ _GRAPH_MAX_PIXELS = 1 << 20
 _NO_GRAPH = bool(os.environ.get("GCS_NO_GRAPH"))
 
 
+
+
 def _torch():
     import torch
     return torch
@@ -140,6 +142,16 @@ class HipOps:
             feats.data_ptr(), cent.data_ptr(), b, h, w, *self._bk, k, n_sets, 1 if reverse else 0, out.data_ptr(),
             1 if out.dtype == torch.uint8 else 0, None if scratch_labels is None else scratch_labels.data_ptr(),
             self._stream()), "gcs_kmeans_assign_raster")
+
+    def download(self, dst_pinned, src):
+        """Device tensor -> pinned host tensor of the same bytes on the current stream, by SDMA (gcs_download)."""
+        self._check_dev(src)
+        n = src.numel() * src.element_size()
+        if not dst_pinned.is_pinned() or dst_pinned.numel() * dst_pinned.element_size() != n \
+                or not src.is_contiguous() or not dst_pinned.is_contiguous():
+            raise ValueError("download needs a contiguous device tensor and a pinned host tensor of the same size")
+        with self.torch.cuda.device(self.device):
+            _lib.check(self.lib.gcs_download(src.data_ptr(), dst_pinned.data_ptr(), n, self._stream()), "gcs_download")
 
     @_on_device
     def features_gather(self, feats, b, h, w, byx):
@@ -302,6 +314,7 @@ class Segmenter:
         self.slab_placement_ms = None
         self._ws = {}
         self._host = {}
+        self._stream = {}
         self._graphs = {}
 
     # ---- workspaces
@@ -567,12 +580,12 @@ class Segmenter:
         cur = torch.cuda.current_stream(dev)
         n_chunks = min(b, 4)
         bounds = [(b * i) // n_chunks for i in range(n_chunks + 1)]
-        src = torch.from_numpy(imgs)
+        pin_np = st["pin_in"].numpy()
         with torch.cuda.device(dev):
             st["copy"].wait_stream(cur)                            # the device input buffer is free again
             for i in range(n_chunks):
                 g0, g1 = bounds[i], bounds[i + 1]
-                st["pin_in"][g0:g1].copy_(src[g0:g1])             # host memcpy into the pinned buffer
+                np.copyto(pin_np[g0:g1], imgs[g0:g1])             # host memcpy into the pinned buffer (see _stage)
                 with torch.cuda.stream(st["copy"]):
                     st["dev_in"][g0:g1].copy_(st["pin_in"][g0:g1], non_blocking=True)
                     st["ev"][i].record(st["copy"])
@@ -596,8 +609,8 @@ class Segmenter:
 
         Three streams work on ``depth + 1`` buffer slots: while batch n runs through the Gabor stage and the Lloyd passes,
         batch n+1 is copied into pinned memory and uploaded and the labels of batch n-1 are downloaded into a fresh pinned
-        array that the caller owns. A result is handed out ``depth`` batches after its input was taken (sooner when the
-        input ends)."""
+        array that the caller owns, both by the copy engines (gcs_download: see there). A result is handed out ``depth``
+        batches after its input was taken (sooner when the input ends)."""
         torch = _torch()
         out_dtype = np.dtype(out_dtype)
         if out_dtype not in (np.dtype(np.int32), np.dtype(np.uint8)):
@@ -615,8 +628,24 @@ class Segmenter:
         ops, dev = self.ops, self.ops.device
         n_slots = max(2, int(depth) + 1)
         st = None
-        pending = []                                               # (event, pinned result) in input order
+        pending = []                                               # (download event, result array) in input order
         t_dtype = torch.uint8 if out_dtype == np.uint8 else torch.int32
+
+        def issue_download(i):
+            """Queue the download of the batch in slot i on the `down` stream and its result in `pending`. Not a
+            `tensor.copy_` / hipMemcpyAsync: on this stack that device-to-host copy runs as a blit KERNEL
+            (`__amd_rocclr_copyBuffer` in the kernel trace) and, for as long as PCIe takes - 0.75 ms for the 39.5 MB of a
+            64-image int32 batch - the kernels of every other stream crawl (profiles/r3_notes.md). gcs_download hands the
+            same bytes to the copy engines, like the uploads."""
+            land = torch.empty((b, h, w), dtype=t_dtype, pin_memory=True)     # caller-owned; torch recycles it once dropped
+            with torch.cuda.stream(st["down"]):
+                st["down"].wait_event(st["ev_done"][i])
+                ops.download(land, st["dev_out"][i])
+                st["ev_down"][i].record(st["down"])
+            ev = torch.cuda.Event()
+            ev.record(st["down"])
+            pending.append((ev, land.numpy()))
+
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             for n, imgs in enumerate(batches):
@@ -631,19 +660,27 @@ class Segmenter:
                         raise ValueError("batch too large for one feature slab: use smaller batches")
                     shape = (b, h, w)
                     ws = self._workspace(b, h, w, mode)
-                    st = dict(pin_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)],
-                              dev_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)],
-                              dev_out=[torch.empty((b, h, w), dtype=t_dtype, device=dev) for _ in range(n_slots)],
-                              up=torch.cuda.Stream(device=dev), down=torch.cuda.Stream(device=dev),
-                              ev_up=[torch.cuda.Event() for _ in range(n_slots)],
-                              ev_done=[torch.cuda.Event() for _ in range(n_slots)],
-                              ev_down=[torch.cuda.Event() for _ in range(n_slots)])
+                    key = (b, h, w, n_slots, t_dtype)
+                    st = self._stream.get(key)
+                    if st is None:                                 # kept for the next stream of this shape: pinning 3 x 30 MB costs ms
+                        st = dict(pin_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)],
+                                  dev_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)],
+                                  dev_out=[torch.empty((b, h, w), dtype=t_dtype, device=dev) for _ in range(n_slots)],
+                                  up=torch.cuda.Stream(device=dev), down=torch.cuda.Stream(device=dev),
+                                  ev_up=[torch.cuda.Event() for _ in range(n_slots)],
+                                  ev_done=[torch.cuda.Event() for _ in range(n_slots)],
+                                  ev_down=[torch.cuda.Event() for _ in range(n_slots)])
+                        self._stream = {key: st}
+                    else:                                          # a stream abandoned half way may still own the slots
+                        st["up"].synchronize()
+                        st["down"].synchronize()
+                        cur.synchronize()
                 elif (b, h, w) != shape:
                     raise ValueError(f"batch {n} has shape {(b, h, w)}, the stream was opened with {shape}")
                 i = n % n_slots
                 if n >= n_slots:
                     st["ev_up"][i].synchronize()                   # the slot's previous upload has left the pinned buffer
-                st["pin_in"][i].copy_(torch.from_numpy(imgs))      # host memcpy, while the device works on earlier batches
+                _stage(st["pin_in"][i], imgs)                      # host memcpy, while the device works on earlier batches
                 with torch.cuda.stream(st["up"]):
                     if n >= n_slots:
                         st["up"].wait_event(st["ev_done"][i])      # dev_in[i] is no longer being read
@@ -656,21 +693,14 @@ class Segmenter:
                 lloyd(ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
                       ws["sums"], raster=st["dev_out"][i])
                 st["ev_done"][i].record(cur)
-                res = torch.empty((b, h, w), dtype=t_dtype, pin_memory=True)      # caller-owned pinned result
-                with torch.cuda.stream(st["down"]):
-                    st["down"].wait_event(st["ev_done"][i])
-                    res.copy_(st["dev_out"][i], non_blocking=True)
-                    st["ev_down"][i].record(st["down"])
-                ev = torch.cuda.Event()
-                ev.record(st["down"])
-                pending.append((ev, res))
-                if len(pending) > depth:
+                issue_download(i)
+                while len(pending) > depth:
                     ev0, res0 = pending.pop(0)
                     ev0.synchronize()
-                    yield res0.numpy()
+                    yield res0
             for ev0, res0 in pending:
                 ev0.synchronize()
-                yield res0.numpy()
+                yield res0
             if st is not None:
                 cur.wait_stream(st["up"])
                 cur.wait_stream(st["down"])
@@ -711,7 +741,7 @@ class Segmenter:
                     self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[key] = ent
             cur = torch.cuda.current_stream(dev)
-            ent["pin_in"].copy_(torch.from_numpy(imgs))
+            _stage(ent["pin_in"], imgs)
             ent["dev_in"].copy_(ent["pin_in"], non_blocking=True)
             if ent["graph"] is not None:
                 ent["graph"].replay()
@@ -742,6 +772,13 @@ class Segmenter:
         if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
             raise ValueError("img must be an (H,W,3) uint8 array (skimage.io.imread of an RGB file)")
         return self.segment_batch(img[None])[0]
+
+
+def _stage(pinned, imgs):
+    """Host array -> pinned staging tensor with ONE plain memcpy (numpy, GIL released). Not `tensor.copy_`: that runs on
+    torch's intra-op pool, which sizes itself by the machine's core count and not by the process's CPU quota - on a
+    256-core host inside a 16-core cgroup the pool's threads get throttled and a 30 MB copy takes 10+ ms instead of 0.5."""
+    np.copyto(pinned.numpy(), imgs)
 
 
 _default: dict = {}

@@ -34,7 +34,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 14
+#define GCS_ABI_VERSION 15
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
@@ -72,6 +72,11 @@ size_t gcs_label_slab_bytes(int B, int H, int W);
  * of 16 elements, padded (opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */
 size_t gcs_kmeans_parts_per_image(int B, int H, int W);
 size_t gcs_kmeans_partial_bytes(int B, int H, int W, int D, int k);
+
+/* Device memory -> pinned host memory on `stream` through the copy engines (SDMA). The pipelined host path
+ * (Segmenter.segment_stream) uses it instead of hipMemcpyAsync, which in this direction is served by a chip-filling blit
+ * kernel that stalls the kernels of every other stream for as long as PCIe takes. */
+int gcs_download(const void *src_dev, void *dst_host, size_t bytes, gcs_stream_t stream);
 
 /* ---- device entry points ---------------------------------------------------------------- */
 

@@ -116,6 +116,34 @@ def test_segment_stream_equals_segment_batch(torch_cuda):
     assert list(seg.segment_stream(iter([]))) == []
     with pytest.raises(ValueError):
         list(seg.segment_stream(iter([batches[0], _synth(6, 64, 104, seed=1)])))
+    # a stream abandoned half way (its slots still hold work in flight), then the same shape again: the kept slot buffers are
+    # drained before reuse; every result is the caller's own pinned array, so results that are KEPT stay valid while later
+    # batches reuse the slots
+    want = [seg.segment_batch(x) for x in batches]
+    gen = seg.segment_stream(iter(batches), depth=2)
+    first = next(gen)
+    del gen
+    assert np.array_equal(first, want[0])
+    got = list(seg.segment_stream(iter(batches * 2), depth=1))
+    assert len(got) == 14 and all(g.dtype == np.int32 for g in got)
+    for g, w_ in zip(got, want * 2):
+        assert np.array_equal(g, w_)
+
+
+def test_download_moves_every_byte(torch_cuda):
+    """gcs_download (the label download of segment_stream, SDMA through the pitched copy): sizes below, at and above its
+    64 KiB row, with and without a remainder; nothing written past the end; a pageable destination is refused."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    ops = Segmenter().ops
+    for n in (3, 65536, 65536 * 7, 65536 * 3 + 5, 1_000_003, 64 * 321 * 481 * 4):
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+        dst = torch.full((n + 64,), 7, dtype=torch.uint8).pin_memory()
+        ops.download(dst[:n], src)
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src.cpu()) and bool((dst[n:] == 7).all()), n
+    with pytest.raises(ValueError):
+        ops.download(torch.empty(n, dtype=torch.uint8), src)             # pageable destination
 
 
 def test_global_codebook_bit_exact(torch_cuda):
