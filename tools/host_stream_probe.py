@@ -63,30 +63,6 @@ def main():
             keep.append(alloc())
         print("pinned result alloc %-12s %.3f ms each when the caller keeps the results" % (dt, (time.perf_counter() - t0) / 5 * 1e3))
         del keep
-    from gabor_color_image_segmentation_amd import _lib
-    lib = _lib.load()
-    src = torch.randint(0, 8, (B, H, W), dtype=torch.uint8).pin_memory()
-    s0, n = src.data_ptr(), src.numel()
-    warm = np.empty((B, H, W), np.int32)
-    for nt in (1, 2, 4, 8):
-        pool = ThreadPoolExecutor(nt)
-        cuts = [(n * t // nt) & ~63 for t in range(nt)] + [n]
-
-        def widen(ptr):
-            list(pool.map(lambda t: lib.gcs_host_labels_widen(s0 + cuts[t], cuts[t + 1] - cuts[t], ptr + 4 * cuts[t]), range(nt)))
-
-        def fresh_np():
-            o = np.empty((B, H, W), np.int32)
-            widen(o.ctypes.data)
-            return o
-
-        def fresh_pin():
-            o = torch.empty((B, H, W), dtype=torch.int32, pin_memory=True)
-            widen(o.data_ptr())
-            return o
-        print("widen 9.9 M labels, %d threads: warm array %.3f ms, fresh np.empty %.3f ms, recycled pinned %.3f ms"
-              % (nt, med(lambda: widen(warm.ctypes.data)), med(fresh_np), med(fresh_pin)), flush=True)
-        pool.shutdown()
     dev = torch.device("cuda:0")
     d_in = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
     d_out = torch.zeros((B, H, W), dtype=torch.int32, device=dev)

@@ -20,10 +20,22 @@ def run():
     imgs = synthetic_shard(0, 64, 321, 481, seed=0)
     seg = Segmenter(device=torch.device("cuda:0"))
     dt = np.uint8 if len(sys.argv) > 2 and sys.argv[2] == "u8" else np.int32
+    if len(sys.argv) > 2 and sys.argv[2] == "batch":               # back-to-back segment_batch calls instead of the stream
+        import time
+        for _ in range(3):
+            seg.segment_batch(imgs, mode="global")
+        t0 = time.perf_counter()
+        for _ in range(8):
+            seg.segment_batch(imgs, mode="global")
+        print("segment_batch: %.3f ms per call" % ((time.perf_counter() - t0) / 8 * 1e3))
+        return
     for _ in seg.segment_stream((imgs for _ in range(3)), mode="global", out_dtype=dt):
         pass
     n = sum(1 for _ in seg.segment_stream((imgs for _ in range(12)), mode="global", out_dtype=dt))
     print("batches", n)
+
+
+MIN_NS = 30000
 
 
 def show(d):
@@ -44,7 +56,7 @@ def show(d):
          [(c[0], c[1], "SDMA copy " + c[2]) for c in cop if c[0] >= tb and c[1] - c[0] > 20000]
     run, last = 0, None
     for s, e, name in sorted(ev):
-        if e - s < 30000 and "copy" not in name.lower():
+        if e - s < MIN_NS and "copy" not in name.lower():
             continue
         if "kmeans_pass" in name:                      # ten in a row: one line
             run += 1
