@@ -3,6 +3,7 @@ d=sys.argv[1]
 rows=[]
 for f in glob.glob(d+'/**/*kernel_trace.csv',recursive=True): rows+=list(csv.DictReader(open(f)))
 ker=sorted((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"][:50]) for r in rows)
+ker=[k for k in ker if 'elementwise' not in k[2]]
 # last occurrence of plane kernel = start of last step
 idx=[i for i,k in enumerate(ker) if 'gabor_plane' in k[2]]
 i0=idx[-2]; i1=idx[-1]
