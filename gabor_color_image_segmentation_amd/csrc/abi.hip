@@ -91,8 +91,14 @@ extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
     const size_t px = (size_t)lo.ntiles * KP_TP;
     const size_t need = (px + 65535) / 65536;
     // small batches (B * parts would leave most of the 768 slots empty): down to 2 tiles per workgroup - one image then
-    // runs on 313 workgroups instead of 78 and a pass takes a third of the time (it is latency-bound: 14 MB per image)
-    size_t most = px / KP_TP / 2;
+    // runs on 313 workgroups instead of 78 and a pass takes a third of the time (it is latency-bound: 14 MB per image).
+    // One tile per workgroup (626 rows): the pass takes the same 15.6 us - its cost is the launch, the centroid prologue
+    // and the fold, not the tiles - and the reduce of twice the rows makes the step slower (0.223 vs 0.208 ms); three
+    // tiles: 0.217 ms.
+#ifndef GCS_KP_SMALL_TILES
+#define GCS_KP_SMALL_TILES 2
+#endif
+    size_t most = px / KP_TP / GCS_KP_SMALL_TILES;
     if (most < 1) most = 1;
     size_t want = (GCS_KP_SLOTS + (size_t)B - 1) / (size_t)B;
     if (want > most) want = most;
