@@ -130,6 +130,25 @@ def test_segment_stream_equals_segment_batch(torch_cuda):
         assert np.array_equal(g, w_)
 
 
+def test_segment_images_equals_one_call_per_image(torch_cuda):
+    """Segmenter.segment_images: a data-set loop over images of mixed shapes, grouped per shape behind the scenes, yields in
+    input order exactly what segment(img) gives for each image (script.py:22-38 calls the slot once per image)."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    seg = Segmenter(n_iter=3)
+    shapes = [(40, 64), (64, 40), (40, 64), (33, 57), (64, 40), (40, 64), (40, 64), (64, 40), (40, 64)]
+    imgs = [_synth(1, h, w, seed=50 + i)[0] for i, (h, w) in enumerate(shapes)]
+    want = [seg(im) for im in imgs]
+    for batch in (1, 2, 3, 64):
+        got = list(seg.segment_images(iter(imgs), batch=batch))
+        assert len(got) == len(want)
+        for g, w_, im in zip(got, want, imgs):
+            assert g.dtype == np.int32 and g.shape == im.shape[:2] and np.array_equal(g, w_), batch
+    assert list(seg.segment_images([])) == []
+    assert [g.dtype for g in seg.segment_images(imgs[:2], out_dtype=np.uint8)] == [np.uint8, np.uint8]
+    with pytest.raises(ValueError):
+        list(seg.segment_images([imgs[0][..., 0]]))
+
+
 def test_download_moves_every_byte(torch_cuda):
     """gcs_download (the label download of segment_stream, SDMA through the pitched copy): sizes below, at and above its
     64 KiB row, with and without a remainder; nothing written past the end; a pageable destination is refused."""

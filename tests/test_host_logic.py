@@ -67,3 +67,21 @@ def test_connectivity_option_relabels_connected_regions():
     out = seg.segment_device(torch.from_numpy(imgs)).numpy()
     for b in range(2):
         assert np.array_equal(out[b], so.connected_regions(so.segment(imgs[b], n_iter=3)))
+
+
+def test_segment_images_groups_by_shape_and_keeps_the_input_order():
+    """Segmenter.segment_images (the data-set form of the loop at script.py:22-38): mixed shapes are batched per shape, every
+    label map equals the one-image call's, results come out in input order, the batches are as large as asked for."""
+    shapes = [(16, 24), (24, 16), (16, 24), (16, 24), (24, 16), (17, 24), (16, 24)]
+    imgs = [synthetic_batch(1, h, w, seed=20 + i)[0] for i, (h, w) in enumerate(shapes)]
+    seg = _seg(n_iter=2)
+    got = list(seg.segment_images(iter(imgs), batch=3))
+    assert len(got) == len(imgs)
+    for g, im in zip(got, imgs):
+        assert g.shape == im.shape[:2] and np.array_equal(g, so.segment(im, n_iter=2))
+    # 4 images of 16x24 -> one batch of 3 and a remainder of 1; 2 of 24x16; 1 of 17x24
+    assert sorted(c[1] for c in seg.ops.calls if c[0] == "gabor") == [1, 1, 2, 3]
+    with pytest.raises(ValueError):
+        list(seg.segment_images([np.zeros((16, 24), np.uint8)]))
+    with pytest.raises(ValueError):
+        list(seg.segment_images(imgs, batch=0))
