@@ -3,7 +3,7 @@
 repeats the GPU run to tell a deterministic error from a race. usage: dbg_val.py [repeats]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gabor_color_image_segmentation_amd import Segmenter
 from oracle import spec_oracle as so, c_oracle as co

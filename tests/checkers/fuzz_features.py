@@ -4,7 +4,7 @@ a single valid row, ...), batch sizes, banks (1-8 scales, odd orientation counts
 a summary; exit code 1 on any mismatch. usage: fuzz_features.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gabor_color_image_segmentation_amd import Segmenter
 from gabor_color_image_segmentation_amd.synthetic import synthetic_batch

@@ -378,13 +378,13 @@ def test_host_path_variants_agree_with_the_device_path(torch_cuda):
 
 
 def test_randomised_shapes_banks_and_codebooks_against_the_c_oracle(torch_cuda):
-    """tools/fuzz_features.py: 60 random cases (tiny / odd / one-row-remainder shapes, batches 1-9, banks of 1-8 scales with
+    """tests/checkers/fuzz_features.py: 60 random cases (tiny / odd / one-row-remainder shapes, batches 1-9, banks of 1-8 scales with
     odd orientation counts, ksize 1-15, k 1-16, both codebook modes, constant extreme images): features and labels equal the C
     oracle's bit for bit. (400 further cases were run once in round 3: 0 mismatches.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_features.py"), "60", "3"], cwd=root,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checkers", "fuzz_features.py"), "60", "3"], cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "60 cases, 0 bad" in r.stdout
