@@ -315,6 +315,7 @@ class Segmenter:
         self._ws = {}
         self._host = {}
         self._stream = {}
+        self._copy_pair = None
         self._stagers = None
         self._graphs = {}
 
@@ -328,10 +329,10 @@ class Segmenter:
                       partials=self.ops.partial_slab(g, h, w, self.k),
                       cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
             self._place_slab(ws, g, h, w, n_sets)
-            # keep the four most recent (batch, shape) pairs resident (a data set alternating landscape and portrait
-            # batches, each with a remainder batch at its end, would otherwise rebuild - and re-place - its workspace on
-            # every switch; 0.95 GB per 64-image entry)
-            if len(self._ws) >= 4:
+            # keep the eight most recent (batch, shape, mode) triples resident (a data set alternating landscape and
+            # portrait batches, each with a remainder batch at its end, beside a global-codebook run, would otherwise
+            # rebuild - and re-place - its workspace on every switch; 0.95 GB per 64-image entry)
+            if len(self._ws) >= 8:
                 self._ws.pop(next(iter(self._ws)))
             self._ws[key] = ws
         return ws
@@ -623,7 +624,6 @@ class Segmenter:
         batch n+1 is copied into pinned memory and uploaded and the labels of batch n-1 are downloaded into a fresh pinned
         array that the caller owns, both by the copy engines (gcs_download: see there). A result is handed out ``depth``
         batches after its input was taken (sooner when the input ends)."""
-        torch = _torch()
         out_dtype = np.dtype(out_dtype)
         if out_dtype not in (np.dtype(np.int32), np.dtype(np.uint8)):
             raise ValueError("out_dtype must be int32 or uint8")
@@ -637,85 +637,13 @@ class Segmenter:
             for imgs in batches:                                   # no pipeline for post-passes / collectives / stand-ins
                 yield self.segment_batch(imgs, mode, out_dtype)
             return
-        ops, dev = self.ops, self.ops.device
-        n_slots = max(2, int(depth) + 1)
-        st = None
-        pending = []                                               # (download event, result array) in input order
-        t_dtype = torch.uint8 if out_dtype == np.uint8 else torch.int32
-
-        def issue_download(i):
-            """Queue the download of the batch in slot i on the `down` stream and its result in `pending`. Not a
-            `tensor.copy_` / hipMemcpyAsync: on this stack that device-to-host copy runs as a blit KERNEL
-            (`__amd_rocclr_copyBuffer` in the kernel trace) and, for as long as PCIe takes - 0.75 ms for the 39.5 MB of a
-            64-image int32 batch - the kernels of every other stream crawl (profiles/r3_notes.md). gcs_download hands the
-            same bytes to the copy engines, like the uploads."""
-            land = torch.empty((b, h, w), dtype=t_dtype, pin_memory=True)     # caller-owned; torch recycles it once dropped
-            with torch.cuda.stream(st["down"]):
-                st["down"].wait_event(st["ev_done"][i])
-                ops.download(land, st["dev_out"][i])
-                st["ev_down"][i].record(st["down"])
-            ev = torch.cuda.Event()
-            ev.record(st["down"])
-            pending.append((ev, land.numpy()))
-
-        with torch.cuda.device(dev):
-            cur = torch.cuda.current_stream(dev)
-            for n, imgs in enumerate(batches):
-                imgs = np.ascontiguousarray(imgs)
-                if imgs.dtype != np.uint8 or imgs.ndim != 4 or imgs.shape[3] != 3:
-                    raise ValueError("every batch must be a (B,H,W,3) uint8 array")
-                b, h, w, _ = imgs.shape
-                if st is None:
-                    if h < 8 or w < 8:
-                        raise ValueError("images must be at least 8x8")
-                    if self.group_size(b, h, w, mode) < b:
-                        raise ValueError("batch too large for one feature slab: use smaller batches")
-                    shape = (b, h, w)
-                    ws = self._workspace(b, h, w, mode)
-                    key = (b, h, w, n_slots, t_dtype)
-                    st = self._stream.get(key)
-                    if st is None:                                 # kept for the next stream of this shape: pinning 3 x 30 MB costs ms
-                        st = dict(pin_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)],
-                                  dev_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)],
-                                  dev_out=[torch.empty((b, h, w), dtype=t_dtype, device=dev) for _ in range(n_slots)],
-                                  up=torch.cuda.Stream(device=dev), down=torch.cuda.Stream(device=dev),
-                                  ev_up=[torch.cuda.Event() for _ in range(n_slots)],
-                                  ev_done=[torch.cuda.Event() for _ in range(n_slots)],
-                                  ev_down=[torch.cuda.Event() for _ in range(n_slots)])
-                        self._stream = {key: st}
-                    else:                                          # a stream abandoned half way may still own the slots
-                        st["up"].synchronize()
-                        st["down"].synchronize()
-                        cur.synchronize()
-                elif (b, h, w) != shape:
-                    raise ValueError(f"batch {n} has shape {(b, h, w)}, the stream was opened with {shape}")
-                i = n % n_slots
-                if n >= n_slots:
-                    st["ev_up"][i].synchronize()                   # the slot's previous upload has left the pinned buffer
-                _stage(st["pin_in"][i], imgs)                      # host memcpy, while the device works on earlier batches
-                with torch.cuda.stream(st["up"]):
-                    if n >= n_slots:
-                        st["up"].wait_event(st["ev_done"][i])      # dev_in[i] is no longer being read
-                    st["dev_in"][i].copy_(st["pin_in"][i], non_blocking=True)
-                    st["ev_up"][i].record(st["up"])
-                cur.wait_event(st["ev_up"][i])
-                if n >= n_slots:
-                    cur.wait_event(st["ev_down"][i])               # dev_out[i] has been downloaded
-                ops.gabor_features(st["dev_in"][i], ws["feats"])
-                lloyd(ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
-                      ws["sums"], raster=st["dev_out"][i])
-                st["ev_done"][i].record(cur)
-                issue_download(i)
-                while len(pending) > depth:
-                    ev0, res0 = pending.pop(0)
-                    ev0.synchronize()
-                    yield res0
-            for ev0, res0 in pending:
-                ev0.synchronize()
-                yield res0
-            if st is not None:
-                cur.wait_stream(st["up"])
-                cur.wait_stream(st["down"])
+        pipe = _StreamPipe(self, mode, out_dtype, depth)
+        try:
+            for imgs in batches:
+                yield from pipe.push(imgs)
+            yield from pipe.drain()
+        finally:
+            pipe.close()
 
     def _segment_small(self, imgs, mode, out_dtype):
         """One image (or a small batch): the slot as script.py:22-30 calls it, once per image. A step is ~25 launches of
@@ -764,6 +692,18 @@ class Segmenter:
             cur.synchronize()
         return res.numpy()
 
+    def _copy_streams(self):
+        """The upload and the download stream of this Segmenter, created once and shared by every host path and shape. HIP maps
+        a process's streams onto a few hardware queues (four by default): with a pair of streams per shape and path, a
+        download stream ended up on the compute stream's queue and every label download then held back the next batch's
+        kernels (the pipelined rate fell from 4 360 to 3 300 Mpix/s as soon as segment_batch had created its own copy stream;
+        profiles/r3_notes.md). Default stream + the Gabor side stream + these two = four."""
+        if self._copy_pair is None:
+            torch = _torch()
+            dev = self.ops.device
+            self._copy_pair = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self._copy_pair
+
     def _host_state(self, b, h, w):
         """Pinned staging buffers, device input / uint8 output buffers, copy stream and events for one batch shape."""
         torch = _torch()
@@ -775,7 +715,7 @@ class Segmenter:
                       dev_in=torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev),
                       dev_out=torch.empty((b, h, w), dtype=torch.uint8, device=dev),
                       dev_out32=torch.empty((b, h, w), dtype=torch.int32, device=dev),
-                      copy=torch.cuda.Stream(device=dev), ev=[torch.cuda.Event() for _ in range(4)])
+                      copy=self._copy_streams()[0], ev=[torch.cuda.Event() for _ in range(4)])
             if len(self._host) >= 4:                               # keep the four most recent shapes (see _workspace)
                 self._host.pop(next(iter(self._host)))
             self._host[key] = st
@@ -792,34 +732,177 @@ class Segmenter:
         order, exactly what ``segment(img)`` returns for every (H,W,3) uint8 image of an iterable - any mix of shapes (BSD500
         holds 481x321 and 321x481 images). Images wait in per-shape groups of up to ``batch`` and go through the device
         together (per-image codebooks, so grouping does not change any label): the data-set loop at the batch rate instead of
-        one 0.28 ms call per image. At most ``batch`` images per shape, and the label maps that finished ahead of an earlier
-        image of another shape, are held back at any time."""
+        one 0.28 ms call per image. Up to two batches per shape (one computing, one downloading), and the label maps that
+        finished ahead of an earlier image of another shape, are held back at any time."""
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be >= 1")
+        out_dtype = np.dtype(out_dtype)
+        if out_dtype not in (np.dtype(np.int32), np.dtype(np.uint8)):
+            raise ValueError("out_dtype must be int32 or uint8")
         groups, ready, nxt = {}, {}, 0
+        pipes, tags = {}, {}                   # per shape: the pipeline of its FULL batches and the image indices in flight
+        piped = hasattr(self.ops, "lib") and not self.connectivity and not self.force_collectives
 
-        def flush(shape):
-            idx, imgs = zip(*groups.pop(shape))
-            labels = self.segment_batch(list(imgs), "per_image", out_dtype)
+        def emit(idx, labels):
             for i, lab in zip(idx, labels):
                 ready[i] = lab
 
-        for n, img in enumerate(images):
-            img = np.asarray(img)
-            if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
-                raise ValueError("every image must be an (H,W,3) uint8 array (skimage.io.imread of an RGB file)")
-            groups.setdefault(img.shape, []).append((n, img))
-            if len(groups[img.shape]) >= batch:
-                flush(img.shape)
+        def flush(shape, final):
+            idx, imgs = zip(*groups.pop(shape))
+            h, w = shape[:2]
+            if piped and not final and len(idx) * h * w > _GRAPH_MAX_PIXELS:
+                # full batches of one shape follow each other through the three-stream pipeline (upload, compute and
+                # download of consecutive batches overlap); their label maps fall due one push later
+                if shape not in pipes:
+                    pipes[shape], tags[shape] = _StreamPipe(self, "per_image", out_dtype, 1), []
+                tags[shape].append(idx)
+                for labels in pipes[shape].push(_ImageList(imgs)):
+                    emit(tags[shape].pop(0), labels)
+            else:
+                emit(idx, self.segment_batch(list(imgs), "per_image", out_dtype))
+
+        try:
+            for n, img in enumerate(images):
+                img = np.asarray(img)
+                if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+                    raise ValueError("every image must be an (H,W,3) uint8 array (skimage.io.imread of an RGB file)")
+                groups.setdefault(img.shape, []).append((n, img))
+                if len(groups[img.shape]) >= batch:
+                    flush(img.shape, False)
+                while nxt in ready:
+                    yield ready.pop(nxt)
+                    nxt += 1
+            for shape, pipe in pipes.items():                      # the input has ended
+                for labels in pipe.drain():
+                    emit(tags[shape].pop(0), labels)
+            while groups:                                          # remainders: oldest waiting image first
+                flush(min(groups, key=lambda sh: groups[sh][0][0]), True)
             while nxt in ready:
                 yield ready.pop(nxt)
                 nxt += 1
-        while groups:                                              # the input has ended: oldest waiting image first
-            flush(min(groups, key=lambda sh: groups[sh][0][0]))
-            while nxt in ready:
-                yield ready.pop(nxt)
-                nxt += 1
+        finally:
+            for pipe in pipes.values():
+                pipe.close()
+
+
+class _StreamPipe:
+    """The three-stream pipeline behind Segmenter.segment_stream / segment_images for ONE batch shape: ``push(batch)`` stages
+    and uploads the batch, queues its Gabor stage, Lloyd passes and label download, and returns the label arrays that have
+    become due (``depth`` pushes later, in order); ``drain()`` returns the rest.
+
+    ``depth + 1`` buffer slots: while batch n computes, batch n+1 is copied into pinned memory and uploaded and the labels of
+    batch n-1 are downloaded into a fresh pinned array that the caller owns, both by the copy engines. The download is not a
+    ``tensor.copy_`` / hipMemcpyAsync: on this stack that device-to-host copy runs as a blit KERNEL (`__amd_rocclr_copyBuffer`
+    in the kernel trace) and, for as long as PCIe takes - 0.75 ms for the 39.5 MB of a 64-image int32 batch - the kernels of
+    every other stream crawl (profiles/r3_notes.md); gcs_download hands the same bytes to SDMA, like the uploads."""
+
+    def __init__(self, seg, mode, out_dtype, depth):
+        self.seg, self.mode, self.depth = seg, mode, int(depth)
+        self.n_slots = max(2, self.depth + 1)
+        torch = _torch()
+        self.t_dtype = torch.uint8 if np.dtype(out_dtype) == np.uint8 else torch.int32
+        self.st = self.ws = self.shape = None
+        self.n = 0
+        self.pending = []                                          # (download event, result array) in input order
+
+    def _open(self, b, h, w):
+        torch = _torch()
+        seg, dev, n_slots = self.seg, self.seg.ops.device, self.n_slots
+        if h < 8 or w < 8:
+            raise ValueError("images must be at least 8x8")
+        if seg.group_size(b, h, w, self.mode) < b:
+            raise ValueError("batch too large for one feature slab: use smaller batches")
+        self.shape = (b, h, w)
+        self.ws = seg._workspace(b, h, w, self.mode)
+        key = (b, h, w, n_slots, self.t_dtype)
+        st = seg._stream.get(key)
+        if st is None or st["busy"]:           # pinning 3 x 30 MB costs ms: the state is kept for the next stream of this shape
+            st = dict(pin_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)],
+                      dev_in=[torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)],
+                      dev_out=[torch.empty((b, h, w), dtype=self.t_dtype, device=dev) for _ in range(n_slots)],
+                      up=seg._copy_streams()[0], down=seg._copy_streams()[1],
+                      ev_up=[torch.cuda.Event() for _ in range(n_slots)],
+                      ev_done=[torch.cuda.Event() for _ in range(n_slots)],
+                      ev_down=[torch.cuda.Event() for _ in range(n_slots)], busy=False)
+            if key not in seg._stream:                             # (a second live stream of the same shape stays private)
+                if len(seg._stream) >= 4:
+                    idle = [k for k, v in seg._stream.items() if not v["busy"]]
+                    if idle:
+                        seg._stream.pop(idle[0])
+                if len(seg._stream) < 4:
+                    seg._stream[key] = st
+        else:                                                      # a stream abandoned half way may still own the slots
+            st["up"].synchronize()
+            st["down"].synchronize()
+            torch.cuda.current_stream(dev).synchronize()
+        st["busy"] = True
+        self.st = st
+
+    def push(self, imgs):
+        torch = _torch()
+        seg, ops, dev = self.seg, self.seg.ops, self.seg.ops.device
+        if not isinstance(imgs, _ImageList):
+            imgs = np.ascontiguousarray(imgs)
+        if imgs.dtype != np.uint8 or imgs.ndim != 4 or imgs.shape[3] != 3:
+            raise ValueError("every batch must be a (B,H,W,3) uint8 array")
+        b, h, w, _ = imgs.shape
+        with torch.cuda.device(dev):
+            if self.st is None:
+                self._open(b, h, w)
+            elif (b, h, w) != self.shape:
+                raise ValueError(f"batch {self.n} has shape {(b, h, w)}, the stream was opened with {self.shape}")
+            st, ws, n, n_slots = self.st, self.ws, self.n, self.n_slots
+            cur = torch.cuda.current_stream(dev)
+            i = n % n_slots
+            if n >= n_slots:
+                st["ev_up"][i].synchronize()                       # the slot's previous upload has left the pinned buffer
+            _stage(st["pin_in"][i], imgs)                          # host memcpy, while the device works on earlier batches
+            with torch.cuda.stream(st["up"]):
+                if n >= n_slots:
+                    st["up"].wait_event(st["ev_done"][i])          # dev_in[i] is no longer being read
+                st["dev_in"][i].copy_(st["pin_in"][i], non_blocking=True)
+                st["ev_up"][i].record(st["up"])
+            cur.wait_event(st["ev_up"][i])
+            if n >= n_slots:
+                cur.wait_event(st["ev_down"][i])                   # dev_out[i] has been downloaded
+            ops.gabor_features(st["dev_in"][i], ws["feats"])
+            lloyd(ops, ws["feats"], b, h, w, seg.k, seg.n_iter, self.mode, ws["labels"], ws["partials"], ws["cent"],
+                  ws["sums"], raster=st["dev_out"][i])
+            st["ev_done"][i].record(cur)
+            land = torch.empty((b, h, w), dtype=self.t_dtype, pin_memory=True)   # caller-owned; torch recycles it once dropped
+            with torch.cuda.stream(st["down"]):
+                st["down"].wait_event(st["ev_done"][i])
+                ops.download(land, st["dev_out"][i])
+                st["ev_down"][i].record(st["down"])
+            ev = torch.cuda.Event()
+            ev.record(st["down"])
+            self.pending.append((ev, land.numpy()))
+            self.n += 1
+            out = []
+            while len(self.pending) > self.depth:
+                ev0, res0 = self.pending.pop(0)
+                ev0.synchronize()
+                out.append(res0)
+            return out
+
+    def drain(self):
+        out = []
+        for ev0, res0 in self.pending:
+            ev0.synchronize()
+            out.append(res0)
+        self.pending = []
+        return out
+
+    def close(self):
+        """Leave the compute stream ordered behind the copy streams and hand the slot buffers back for reuse."""
+        if self.st is not None:
+            torch = _torch()
+            cur = torch.cuda.current_stream(self.seg.ops.device)
+            cur.wait_stream(self.st["up"])
+            cur.wait_stream(self.st["down"])
+            self.st["busy"] = False
+            self.st = None
 
 
 class _ImageList:

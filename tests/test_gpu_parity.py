@@ -145,6 +145,16 @@ def test_segment_images_equals_one_call_per_image(torch_cuda):
             assert g.dtype == np.int32 and g.shape == im.shape[:2] and np.array_equal(g, w_), batch
     assert list(seg.segment_images([])) == []
     assert [g.dtype for g in seg.segment_images(imgs[:2], out_dtype=np.uint8)] == [np.uint8, np.uint8]
+    # batches above the graph-replay size go through the three-stream pipeline, one pipeline per shape: 2 shapes x (2 full
+    # batches of 20 + a remainder), interleaved in the input
+    big = [_synth(1, *((240, 248) if i % 3 else (248, 240)), seed=200 + i)[0] for i in range(75)]
+    want = [seg(im) for im in big[:6]] + [None] * 63 + [seg(im) for im in big[69:]]
+    got = list(seg.segment_images(iter(big), batch=20))
+    assert len(got) == 75 and all(g.shape == im.shape[:2] for g, im in zip(got, big))
+    for g, w_ in zip(got, want):
+        assert w_ is None or np.array_equal(g, w_)
+    again = list(seg.segment_images(big, batch=20, out_dtype=np.uint8))
+    assert all(np.array_equal(a, g) for a, g in zip(again, got))
     with pytest.raises(ValueError):
         list(seg.segment_images([imgs[0][..., 0]]))
 
