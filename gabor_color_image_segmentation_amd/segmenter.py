@@ -751,7 +751,8 @@ class Segmenter:
         def flush(shape, final):
             idx, imgs = zip(*groups.pop(shape))
             h, w = shape[:2]
-            if piped and not final and len(idx) * h * w > _GRAPH_MAX_PIXELS:
+            if piped and not final and len(idx) * h * w > _GRAPH_MAX_PIXELS \
+                    and self.group_size(len(idx), h, w, "per_image") >= len(idx):
                 # full batches of one shape follow each other through the three-stream pipeline (upload, compute and
                 # download of consecutive batches overlap); their label maps fall due one push later
                 if shape not in pipes:
