@@ -7,9 +7,10 @@
 //   gabor_down_kernel       level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
 //                           padded plane of level L and, when a further level follows, as a compact image.
 //   gabor_mfma_kernel       one pyramid level: A = packed 2-digit int8 taps of the level's filters (rows = filter x
-//                           {re_lo,re_hi,im_lo,im_hi}, resident in registers), B = (pixel-128) windows built from an LDS
-//                           tile (LDS-DMA double buffer) by dword reads + v_alignbit, exact int32 accumulate, fused
-//                           epilogue (digit recombine, >>shift, |.|^2, exact isqrt) -> the level's part of the slab.
+//                           {re_lo,re_hi,im_lo,im_hi} x two pixel shifts, resident in registers), B = (pixel-128) windows
+//                           read as aligned 16-byte pieces of an LDS tile kept twice (second copy two bytes to the right;
+//                           LDS-DMA double buffer), exact int32 accumulate, fused epilogue (digit recombine, >>shift,
+//                           |.|^2, exact isqrt) -> the level's part of the slab.
 // Nothing here allocates or frees device memory or blocks the host; every entry point is ordered on the caller's stream
 // (gcs_gabor_features forks level 1 of a large two-level batch onto a side stream and joins it back, see there).
 #include "common.h"

@@ -20,13 +20,37 @@ import numpy as np
 from . import _lib
 from .bank import GaborBank, make_bank
 
-# Measurement switch: GCS_NO_REVERSE=1 sweeps every Lloyd pass in the same direction (results identical).
-_NO_REVERSE = bool(os.environ.get("GCS_NO_REVERSE"))
 _SLAB_BUDGET = 16 << 30    # feature-slab bytes per group; measured: one big launch beats cache-sized groups
-# host calls up to this many pixels replay a captured HIP graph of the whole step (GCS_NO_GRAPH=1: launch eagerly)
+# host calls up to this many pixels replay a captured HIP graph of the whole step
 _GRAPH_MAX_PIXELS = 1 << 20
-_NO_GRAPH = bool(os.environ.get("GCS_NO_GRAPH"))
 
+
+class DebugSwitches:
+    """The ONE set of measurement / test switches of the host side; none of them changes a result.
+
+    Set from the environment, ``GCS_DEBUG=no_reverse,no_graph,force_collectives,slab_candidates=2`` (any subset), or per
+    plan through ``Segmenter.debug``:
+
+    * ``no_reverse``: every Lloyd pass sweeps the slab in the same direction (tools/pass_direction_probe.py);
+    * ``no_graph``: small host calls launch eagerly instead of replaying their captured HIP graph;
+    * ``force_collectives``: ``lloyd`` takes the multi-rank branch (reduce, all-reduce, finalize) even in a one-rank
+      group, so that one GPU can exercise the RCCL path end to end (tests/test_distributed.py, tools/rccl_overhead.py);
+    * ``slab_candidates=N``: overrides ``Segmenter(slab_candidates=...)`` (see ``Segmenter._place_slab``)."""
+
+    def __init__(self, spec=""):
+        self.no_reverse = self.no_graph = self.force_collectives = False
+        self.slab_candidates = None
+        for item in filter(None, (x.strip() for x in spec.split(","))):
+            name, _, val = item.partition("=")
+            if name == "slab_candidates" and val.isdigit():
+                self.slab_candidates = int(val)
+            elif name in ("no_reverse", "no_graph", "force_collectives") and not val:
+                setattr(self, name, True)
+            else:
+                raise ValueError(f"GCS_DEBUG: unknown switch {item!r}")
+
+
+_ENV_DEBUG = DebugSwitches(os.environ.get("GCS_DEBUG", ""))
 
 
 
@@ -96,15 +120,27 @@ class HipOps:
                 raise ValueError(f"tensor on {t.device}, this Segmenter's kernels run on {self.device}")
 
     # ---- device entry points
+    def gabor_scratch(self, b, h, w):
+        """A private Gabor workspace for one (batch, shape): what a captured graph must own (see ``gabor_features``)."""
+        return self.empty_bytes(self.lib.gcs_gabor_workspace_bytes(b, h, w, self.bank.n_scales))
+
     @_on_device
-    def gabor_features(self, imgs, feats):
+    def gabor_features(self, imgs, feats, scratch=None):
+        """``scratch``: a workspace the CALLER owns (``gabor_scratch``). Without it the call uses the shared, growing
+        workspace of this HipOps - fine for eager launches (torch's allocator hands a replaced block to later work of the
+        same stream only), NOT for a captured graph: a replay would keep writing through the raw pointer of a block that
+        a later, larger call has meanwhile given back to the allocator."""
         b, h, w, _ = imgs.shape
         need = self.lib.gcs_gabor_workspace_bytes(b, h, w, self.bank.n_scales)
-        if self._gabor_ws is None or self._gabor_ws.numel() < need:
-            self._gabor_ws = self.empty_bytes(need)
+        if scratch is None:
+            if self._gabor_ws is None or self._gabor_ws.numel() < need:
+                self._gabor_ws = self.empty_bytes(need)
+            scratch = self._gabor_ws
+        elif scratch.numel() < need or scratch.device != self.device:
+            raise ValueError("gabor scratch too small or on another device")
         _lib.check(self.lib.gcs_gabor_features(imgs.data_ptr(), b, h, w, self.packed.data_ptr(),
                                                self.bias.data_ptr(), *self._bk,
-                                               self.bank.ksize, self.bank.shift, self._gabor_ws.data_ptr(),
+                                               self.bank.ksize, self.bank.shift, scratch.data_ptr(),
                                                feats.data_ptr(), self._stream()),
                    "gcs_gabor_features")
 
@@ -219,7 +255,7 @@ def _collective(fn, t, **kw):
 
 
 def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, dist_group=None,
-          rows=None, init=None, force_collectives=False, raster=None):
+          rows=None, init=None, raster=None, debug=_ENV_DEBUG):
     """SPEC.md §4 schedule on one feature slab. ``mode``: 'per_image' or 'global'.
 
     In 'global' mode with torch.distributed initialised, the init centroids come from
@@ -227,8 +263,7 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
     (RCCL on GPU, any order: integer sums are exact). One collective per Lloyd pass.
     ``rows=(lo, hi)``: only these rows of every image vote (row-sharded images, halo rows
     excluded); ``init(cent)``: custom centroid initialisation (row-sharded images).
-    ``force_collectives``: take the multi-rank branch (reduce, all-reduce, finalize) even in a one-rank
-    group, so that a single GPU can exercise the RCCL path end to end (tests).
+    ``debug``: the plan's ``DebugSwitches`` (``force_collectives``, ``no_reverse``).
     ``raster``: (B,H,W) int32 / uint8 device tensor: the last pass writes the label map there itself (whole images only,
     ops that have ``assign_raster``) instead of filling the label slab for a separate raster kernel.
     """
@@ -236,7 +271,7 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
     dist = None
     if mode == "global":
         import torch.distributed as td
-        if td.is_available() and td.is_initialized() and (td.get_world_size(dist_group) > 1 or force_collectives):
+        if td.is_available() and td.is_initialized() and (td.get_world_size(dist_group) > 1 or debug.force_collectives):
             dist = td
     if init is not None:
         init(cent)
@@ -252,7 +287,7 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
         # pass runs back to front because the Gabor stage, which has just written the slab, finished at its end
         # only the last pass's labels are read, and its sums are not: either output of the kernel is optional
         last = t == n_iter - 1
-        rev = not (t & 1) and not _NO_REVERSE
+        rev = not (t & 1) and not debug.no_reverse
         if last and raster is not None:
             ops.assign_raster(feats, cent, b, h, w, k, n_sets, raster, scratch_labels=labels, reverse=rev)
             break
@@ -267,18 +302,18 @@ def lloyd(ops, feats, b, h, w, k, n_iter, mode, labels, partials, cent, sums, di
                 ops.finalize(sums, n_sets, k, cent)
 
 
-def halo_rows(n_levels: int = 2, ksize: int = 15) -> int:
+def halo_rows(n_levels: int = 2, ksize: int = 13) -> int:
     """Real neighbour rows an interior strip edge needs: the reach (ksize - 1) / 2 of the coarsest level's kernel in
-    full-resolution rows (12 for the default 13x13 bank on two levels, 14 for a 15x15 one)."""
+    full-resolution rows (12 for the default 13x13 bank on two levels - the defaults here -, 14 for a 15x15 one)."""
     return ((ksize - 1) // 2) << (n_levels - 1)
 
 
-def shard_rows(height: int, world: int, rank: int, n_levels: int = 2, ksize: int = 15):
+def shard_rows(height: int, world: int, rank: int, n_levels: int = 2, ksize: int = 13):
     """Row strip of rank ``rank``: owned global rows [r0, r1) and the strip [s0, s1) that also carries real
     neighbour rows on interior edges (BASELINE config 5).
 
-    ``n_levels`` = pyramid levels of the bank (SPEC.md §2; 2 for the default 4-scale bank), ``ksize`` its kernel size
-    (default: the largest one the ABI takes, i.e. the most rows). Strip and ownership boundaries are multiples of
+    ``n_levels`` = pyramid levels of the bank (SPEC.md §2), ``ksize`` its kernel size; the defaults are those of the default
+    bank (4 scales on 2 levels, 13x13) - for any other bank use ``Segmenter.shard_rows``, which reads them from its bank. Strip and ownership boundaries are multiples of
     ``2**(n_levels-1)`` so that every strip's pyramid is a window of the global pyramid, and the halo is the reach of
     the coarsest level's kernel: ``halo_rows(n_levels, ksize)`` rows."""
     align = 1 << (n_levels - 1)
@@ -304,13 +339,13 @@ class Segmenter:
         if n_iter < 1:
             raise ValueError("n_iter must be >= 1")
         self.k, self.n_iter = int(k), int(n_iter)
-        self.force_collectives = False     # tests: run the multi-rank branch of lloyd() in a one-rank group
+        self.debug = DebugSwitches(os.environ.get("GCS_DEBUG", ""))     # measurement / test switches (see the class)
         self.connectivity = bool(connectivity)     # SPEC.md §7 post-pass
         self.bank = make_bank(n_scales, n_orient, ksize, f_max, ratio, bandwidth)
         self.ops = ops if ops is not None else HipOps(self.bank, device)
         # feature-slab allocations to time at first use of a large workspace shape (see _place_slab). 1 = take the first
         # one (the library default: no extra memory, no host synchronisation, graph-capturable); bench.py asks for 2.
-        self.slab_candidates = int(os.environ.get("GCS_SLAB_CANDIDATES", slab_candidates))
+        self.slab_candidates = int(self.debug.slab_candidates or slab_candidates)
         self.slab_placement_ms = None
         self._ws = {}
         self._host = {}
@@ -318,6 +353,12 @@ class Segmenter:
         self._copy_pair = None
         self._stagers = None
         self._graphs = {}
+
+    @property
+    def native(self):
+        """True when the ops are HipOps (libgcs.so). The only other ops are the CPU tests' stand-in for the host logic
+        (tests/fake_ops.py), which has no slabs, streams or graphs: the pipelined / captured host paths need ``native``."""
+        return hasattr(self.ops, "lib")
 
     # ---- workspaces
     def _workspace(self, g, h, w, mode):
@@ -348,7 +389,7 @@ class Segmenter:
         kept; the others go back to the allocator. Off by default (1): it costs transient memory, synchronises the host
         at first use of a shape and puts extra launches into a profile. bench.py asks for 2 and reports their times."""
         n_cand = self.slab_candidates
-        if not hasattr(self.ops, "lib") or ws["feats"].numel() < (256 << 20) or n_cand <= 1:
+        if not self.native or ws["feats"].numel() < (256 << 20) or n_cand <= 1:
             return
         torch = _torch()
         n_cand = min(n_cand, (24 << 30) // max(1, ws["feats"].numel()))      # at most 24 GB of candidates
@@ -384,7 +425,7 @@ class Segmenter:
         if mode == "global":
             return b
         per_image = self.ops.lib.gcs_feature_slab_bytes(1, h, w, self.bank.n_scales, self.bank.n_orient) \
-            if hasattr(self.ops, "lib") else 2 * self.bank.n_features * h * w
+            if self.native else 2 * self.bank.n_features * h * w
         return max(1, min(b, _SLAB_BUDGET // max(1, per_image)))
 
     # ---- device-resident API (used by bench.py: inputs already in HBM)
@@ -399,7 +440,7 @@ class Segmenter:
         b, h, w, _ = imgs.shape
         if h < 8 or w < 8:
             raise ValueError("images must be at least 8x8")
-        on_gpu = hasattr(self.ops, "lib")
+        on_gpu = self.native
         if on_gpu and imgs.device != self.ops.device:
             raise ValueError(f"imgs live on {imgs.device}, this Segmenter on {self.ops.device}")
         if out is None:
@@ -417,8 +458,7 @@ class Segmenter:
                 self.ops.gabor_features(imgs[g0:g0 + n], ws["feats"])
                 direct = hasattr(self.ops, "assign_raster")      # the last pass writes the raster map itself
                 lloyd(self.ops, ws["feats"], n, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
-                      ws["cent"], ws["sums"], dist_group, force_collectives=self.force_collectives,
-                      raster=out[g0:g0 + n] if direct else None)
+                      ws["cent"], ws["sums"], dist_group, raster=out[g0:g0 + n] if direct else None, debug=self.debug)
                 if not direct:
                     self.ops.labels_widen(ws["labels"], n, h, w, out[g0:g0 + n])
             if self.connectivity:
@@ -432,6 +472,10 @@ class Segmenter:
         return dict(feats=self.ops.feature_slab(n, h, w), labels=self.ops.label_slab(n, h, w),
                     partials=self.ops.partial_slab(n, h, w, self.k),
                     cent=self.ops.new_centroids(n_sets, self.k), sums=self.ops.new_sums(n_sets, self.k))
+
+    def shard_rows(self, height, world, rank):
+        """``shard_rows`` for THIS plan's bank (its pyramid depth and kernel size decide alignment and halo)."""
+        return shard_rows(height, world, rank, self.bank.n_levels, self.bank.ksize)
 
     def segment_rows_sharded_device(self, strip, r0, r1, s0, height, dist_group=None, out=None):
         """Row-sharded images with one global codebook (BASELINE config 5).
@@ -478,7 +522,7 @@ class Segmenter:
             cent.copy_(table.to(torch.int16).view(1, k, dfeat))               # wraps back to the uint16 bits
 
         lloyd(self.ops, ws["feats"], b, hs, w, k, self.n_iter, "global", ws["labels"], ws["partials"],
-              ws["cent"], ws["sums"], dist_group, rows=(r0 - s0, r1 - s0), init=init)
+              ws["cent"], ws["sums"], dist_group, rows=(r0 - s0, r1 - s0), init=init, debug=self.debug)
         full = torch.empty((b, hs, w), dtype=torch.int32, device=strip.device)
         self.ops.labels_widen(ws["labels"], b, hs, w, full)
         res = full[:, r0 - s0:r1 - s0]
@@ -572,13 +616,13 @@ class Segmenter:
         if mode == "global":
             import torch.distributed as td
             dist_on = td.is_available() and td.is_initialized()
-        if not hasattr(self.ops, "lib") or self.connectivity or dist_on or self.force_collectives \
+        if not self.native or self.connectivity or dist_on or self.debug.force_collectives \
                 or self.group_size(b, h, w, mode) < b:
             dev = torch.from_numpy(np.asarray(imgs)).to(self.ops.device)   # plain path (test stand-ins, post-passes, collectives)
             return self.segment_device(dev, mode).cpu().numpy().astype(out_dtype, copy=False)
 
         ops, dev = self.ops, self.ops.device
-        if b * h * w <= _GRAPH_MAX_PIXELS and not _NO_GRAPH:
+        if b * h * w <= _GRAPH_MAX_PIXELS and not self.debug.no_graph:
             return self._segment_small(imgs, mode, out_dtype)
         st = self._host_state(b, h, w)
         ws = self._workspace(b, h, w, mode)
@@ -606,12 +650,12 @@ class Segmenter:
                 ops.gabor_features(st["dev_in"][g0:g1], ws["feats"][g0 * per_img:])
             dev_out = st["dev_out"] if out_dtype == np.uint8 else st["dev_out32"]
             lloyd(ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"],
-                  ws["cent"], ws["sums"], raster=dev_out)
+                  ws["cent"], ws["sums"], raster=dev_out, debug=self.debug)
             # The result is a FRESH pinned host buffer per call, handed to the caller as the base of the returned
             # array (torch's caching host allocator recycles it once the caller drops the array): the device-to-host
             # copy lands directly in caller-owned memory, with no pageable copy and no first-touch page faults.
             res = torch.empty((b, h, w), dtype=dev_out.dtype, pin_memory=True)
-            res.copy_(dev_out, non_blocking=True)
+            ops.download(res, dev_out)                             # copy engines, as in segment_stream (not the blit kernel)
             cur.synchronize()
         return res.numpy()
 
@@ -633,7 +677,7 @@ class Segmenter:
         if mode == "global":
             import torch.distributed as td
             dist_on = td.is_available() and td.is_initialized()
-        if not hasattr(self.ops, "lib") or self.connectivity or dist_on or self.force_collectives:
+        if not self.native or self.connectivity or dist_on or self.debug.force_collectives:
             for imgs in batches:                                   # no pipeline for post-passes / collectives / stand-ins
                 yield self.segment_batch(imgs, mode, out_dtype)
             return
@@ -661,13 +705,17 @@ class Segmenter:
                 dev_in = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)
                 dev_out = torch.empty((b, h, w), dtype=torch.uint8 if out_dtype == np.uint8 else torch.int32, device=dev)
                 pin_in = torch.empty((b, h, w, 3), dtype=torch.uint8, pin_memory=True)
+                # the graph bakes raw pointers in: every buffer it touches, the Gabor scratch included, belongs to the
+                # entry and lives exactly as long as the graph does (the shared scratch of HipOps is replaced, and its
+                # block recycled, whenever a later call needs a larger one)
+                scratch = self.ops.gabor_scratch(b, h, w)
 
                 def step():
-                    self.ops.gabor_features(dev_in, ws["feats"])
+                    self.ops.gabor_features(dev_in, ws["feats"], scratch=scratch)
                     lloyd(self.ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
-                          ws["sums"], raster=dev_out)
+                          ws["sums"], raster=dev_out, debug=self.debug)
                 dev_in.zero_()
-                step()                                     # eager once: allocates the Gabor scratch outside the capture
+                step()                                     # eager once: first-use work (side-stream creation) outside the capture
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
                 try:
@@ -676,7 +724,7 @@ class Segmenter:
                 except RuntimeError:                       # capture refused (e.g. another capture is open): launch eagerly
                     graph = None
                     torch.cuda.synchronize(dev)
-                ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in)
+                ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in, scratch=scratch)
                 if len(self._graphs) >= 4:
                     self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[key] = ent
@@ -732,8 +780,11 @@ class Segmenter:
         order, exactly what ``segment(img)`` returns for every (H,W,3) uint8 image of an iterable - any mix of shapes (BSD500
         holds 481x321 and 321x481 images). Images wait in per-shape groups of up to ``batch`` and go through the device
         together (per-image codebooks, so grouping does not change any label): the data-set loop at the batch rate instead of
-        one 0.28 ms call per image. Up to two batches per shape (one computing, one downloading), and the label maps that
-        finished ahead of an earlier image of another shape, are held back at any time."""
+        one 0.28 ms call per image. Held back at any time: up to two batches per shape in flight (one computing, one
+        downloading), the partial group of every shape, and at most ``2 * batch`` finished label maps that wait for an
+        EARLIER image of another shape - when that many have piled up, the group (or the pipeline) that holds the oldest
+        outstanding image is flushed early as a partial batch, so a rare shape at the start of a long or endless loader
+        neither stalls the output nor grows the pinned result memory without bound."""
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be >= 1")
@@ -742,7 +793,7 @@ class Segmenter:
             raise ValueError("out_dtype must be int32 or uint8")
         groups, ready, nxt = {}, {}, 0
         pipes, tags = {}, {}                   # per shape: the pipeline of its FULL batches and the image indices in flight
-        piped = hasattr(self.ops, "lib") and not self.connectivity and not self.force_collectives
+        piped = self.native and not self.connectivity and not self.debug.force_collectives
 
         def emit(idx, labels):
             for i, lab in zip(idx, labels):
@@ -771,6 +822,16 @@ class Segmenter:
                 groups.setdefault(img.shape, []).append((n, img))
                 if len(groups[img.shape]) >= batch:
                     flush(img.shape, False)
+                if len(ready) >= 2 * batch and nxt not in ready:
+                    # bound the wait: the oldest outstanding image sits in a partial group or in a pipeline
+                    held = [sh for sh, g in groups.items() if g and g[0][0] == nxt]
+                    if held:
+                        flush(held[0], True)
+                    else:
+                        for shape, pipe in pipes.items():
+                            if tags[shape] and tags[shape][0][0] == nxt:
+                                for labels in pipe.drain():
+                                    emit(tags[shape].pop(0), labels)
                 while nxt in ready:
                     yield ready.pop(nxt)
                     nxt += 1
@@ -869,7 +930,7 @@ class _StreamPipe:
                 cur.wait_event(st["ev_down"][i])                   # dev_out[i] has been downloaded
             ops.gabor_features(st["dev_in"][i], ws["feats"])
             lloyd(ops, ws["feats"], b, h, w, seg.k, seg.n_iter, self.mode, ws["labels"], ws["partials"], ws["cent"],
-                  ws["sums"], raster=st["dev_out"][i])
+                  ws["sums"], raster=st["dev_out"][i], debug=seg.debug)
             st["ev_done"][i].record(cur)
             land = torch.empty((b, h, w), dtype=self.t_dtype, pin_memory=True)   # caller-owned; torch recycles it once dropped
             with torch.cuda.stream(st["down"]):
@@ -902,6 +963,12 @@ class _StreamPipe:
             cur = torch.cuda.current_stream(self.seg.ops.device)
             cur.wait_stream(self.st["up"])
             cur.wait_stream(self.st["down"])
+            # Results nobody took (an abandoned or failed generator): their pinned landing buffers come from torch's host
+            # allocator, which knows nothing about the raw gcs_download still writing them - wait for those copies before
+            # the arrays are dropped, or the next pinned allocation could be handed a block with a transfer in flight.
+            for ev0, _ in self.pending:
+                ev0.synchronize()
+            self.pending = []
             self.st["busy"] = False
             self.st = None
 

@@ -52,8 +52,8 @@ const char *gcs_last_error(void);
 
 /* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
 
-/* Filters are packed level by level, each level padded to a multiple of 8 filters (one 32-row MFMA tile =
- * 8 filters x {re,im} x {lo,hi} digits). Bytes of the packed A-operand image / number of int32 bias words. */
+/* Filters are packed level by level, each level padded to a multiple of 4 filters (one 32-row MFMA tile =
+ * 4 filters x {re,im} x {lo,hi} digits x 2 pixel shifts). Bytes of the packed A-operand image / number of int32 bias words. */
 size_t gcs_bank_packed_bytes(int n_scales, int n_orient);
 size_t gcs_bank_bias_count(int n_scales, int n_orient);
 

@@ -48,8 +48,7 @@ def _strip_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
     from gabor_color_image_segmentation_amd import Segmenter, make_bank, shard_rows
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     imgs = synthetic_batch(b, height, width, seed=13)
-    # the halo of the bank's own kernel (13x13 on two levels: 12 rows), not the 15x15 frame's 14
-    r0, r1, s0, s1 = shard_rows(height, world, rank, 2, 13)
+    r0, r1, s0, s1 = shard_rows(height, world, rank)          # defaults = the default bank: 13x13 on two levels, 12 halo rows
     strip = torch.from_numpy(np.ascontiguousarray(imgs[:, s0:s1]))
     if use_gpu:
         seg = Segmenter(k=k, n_iter=n_iter, device="cuda:0")
@@ -65,7 +64,7 @@ def _strip_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_image_equals_unsharded_oracle(tmp_path, world):
     """BASELINE config 5 in miniature: one image split into row strips with the halo the bank's kernel needs (6 rows per
-    pyramid level = 12 rows: `halo_rows(2, 13)`; `shard_rows` without a kernel size ships the 15x15 frame's 14)."""
+    pyramid level = 12 rows: `halo_rows(2, 13)`, the defaults of `shard_rows`; `Segmenter.shard_rows` reads them from its bank)."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so
     port = 31500 + (os.getpid() % 2000) + world
@@ -149,7 +148,7 @@ def _rccl_worker(rank, port, tmp):
     from oracle import spec_oracle as so
     imgs = synthetic_batch(3, 72, 104, seed=21)
     seg = Segmenter(k=6, n_iter=5, device="cuda:0")
-    seg.force_collectives = True
+    seg.debug.force_collectives = True
     got = seg.segment_device(torch.from_numpy(imgs).to(dev), mode="global").cpu().numpy()
     ok = ok and bool(np.array_equal(got, so.segment_batch(imgs, mode="global", k=6, n_iter=5)))
     open(os.path.join(tmp, "rccl_ok"), "w").write("1" if ok else "0")

@@ -101,6 +101,33 @@ def test_small_host_calls_replay_a_captured_graph_and_equal_the_eager_path(torch
     assert len(seg._graphs) <= 4
 
 
+def test_a_replayed_graph_never_writes_through_a_recycled_scratch_block(torch_cuda):
+    """ADVICE r3 (use-after-free): the one-image graph used to bake in the pointer of HipOps' SHARED Gabor scratch; a later,
+    larger call replaced that scratch, its block went back to torch's allocator, and the next replay wrote the padded
+    pyramid planes into whoever owned the block by then. Every graph entry now owns its scratch: after a large batch has
+    grown the shared scratch, fill every block the allocator may hand out, replay the small graph, and nothing moved."""
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    seg = Segmenter(n_iter=2)
+    one = _synth(1, 96, 128, seed=31)
+    want = seg.segment_batch(one)                             # captures the (1, 96, 128) graph
+    shared_before = seg.ops._gabor_ws
+    big = _synth(6, 200, 300, seed=32)
+    seg.segment_device(torch.from_numpy(big).cuda())          # grows (replaces) the shared scratch
+    assert seg.ops._gabor_ws is not shared_before or shared_before is None
+    del shared_before
+    ent = next(iter(seg._graphs.values()))
+    assert ent["scratch"].data_ptr() != seg.ops._gabor_ws.data_ptr()
+    # occupy whatever the caching allocator has free (the old shared scratch among it) with a known pattern
+    canaries = [torch.full((n,), 0x5A, dtype=torch.uint8, device="cuda") for n in (1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22)]
+    torch.cuda.synchronize()
+    again = seg.segment_batch(one)                            # replay
+    torch.cuda.synchronize()
+    assert np.array_equal(again, want)
+    for c in canaries:
+        assert bool((c == 0x5A).all())
+
+
 def test_segment_stream_equals_segment_batch(torch_cuda):
     """The pipelined host API (three streams, depth + 1 buffer slots): seven batches through segment_stream give, in order,
     exactly what segment_batch gives for each - both label dtypes, both codebook modes, a depth larger than the input."""
@@ -330,7 +357,7 @@ def test_randomised_shapes_banks_and_codebooks(torch_cuda):
 
 def test_isqrt31_exhaustive(torch_cuda):
     """The 7-instruction exact integer square root of the Gabor epilogue (csrc/gabor.hip isqrt31) on EVERY n of its
-    domain and beyond: every n in [0, 2^31) (SPEC.md §3: re^2 + im^2 <= 2 * 32724^2 < 2^31): one kernel, 2.1e9 values."""
+    domain and beyond: every n in [0, 2^31) (SPEC.md §3: re^2 + im^2 <= 2 * 32767^2 < 2^31, kept by gcs_bank_pack's tap-sum bound): one kernel, 2.1e9 values."""
     import ctypes as C
     from gabor_color_image_segmentation_amd import _lib
     torch = torch_cuda

@@ -85,3 +85,31 @@ def test_segment_images_groups_by_shape_and_keeps_the_input_order():
         list(seg.segment_images([np.zeros((16, 24), np.uint8)]))
     with pytest.raises(ValueError):
         list(seg.segment_images(imgs, batch=0))
+
+
+def test_segment_images_bounds_what_waits_behind_a_rare_shape():
+    """image 0 is the only one of its shape. Without a bound nothing would be yielded before the input ends and
+    every later label map would pile up; with it the rare shape's partial group is flushed once 2 * batch finished maps
+    wait, and the output resumes while the loader is still running."""
+    batch, n = 2, 30
+    rare = synthetic_batch(1, 24, 16, seed=40)[0]
+    common = [synthetic_batch(1, 16, 24, seed=41 + i)[0] for i in range(n)]
+    seg = _seg(n_iter=2)
+    taken, yielded_at = [0], []
+
+    def loader():
+        yield rare
+        for im in common:
+            taken[0] += 1
+            yield im
+
+    got = []
+    for lab in seg.segment_images(loader(), batch=batch):
+        yielded_at.append(taken[0])
+        got.append(lab)
+    assert len(got) == n + 1
+    assert np.array_equal(got[0], so.segment(rare, n_iter=2))
+    for g, im in zip(got[1:], common):
+        assert np.array_equal(g, so.segment(im, n_iter=2))
+    # the first result left while at most 2 * batch + batch images had been taken from the loader, not at its end
+    assert yielded_at[0] <= 3 * batch + 1 < n

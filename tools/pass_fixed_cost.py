@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gabor_color_image_segmentation_amd import Segmenter
 from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
 for (B,H,W) in [(768,16,16),(64,321,481)]:

@@ -12,7 +12,7 @@ imgs = torch.from_numpy(synthetic_shard(0, 64, 321, 481)).to(dev)
 seg = Segmenter(device=dev)
 out = torch.empty((64, 321, 481), dtype=torch.int32, device=dev)
 for force in (False, True, False, True):
-    seg.force_collectives = force
+    seg.debug.force_collectives = force
     for _ in range(10): seg.segment_device(imgs, mode="global", out=out)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): seg.segment_device(imgs, mode="global", out=out)

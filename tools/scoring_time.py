@@ -1,9 +1,10 @@
 import sys, time, numpy as np, torch, os
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from gabor_color_image_segmentation_amd import Segmenter
 from gabor_color_image_segmentation_amd.evaluate import metrics
 from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_device
-inp = np.load("/root/repo/tests/golden/bsd_inputs.npz")
+inp = np.load(os.path.join(ROOT, "tests", "golden", "bsd_inputs.npz"))
 i = "100080"
 segs = [inp["seg_%s_%d" % (i, a)] for a in range(int(inp["nseg_" + i]))]
 img = inp["img_" + i]
