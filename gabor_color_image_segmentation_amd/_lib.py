@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -40,7 +40,6 @@ SIGNATURES = {
     "gcs_kmeans_reduce_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_download": (_i, [_vp, _vp, _sz, _vp]),
     "gcs_labels_widen": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "gcs_labels_raster_u8": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gcs_selftest_isqrt": (_i, [C.c_uint, _vp, _vp]),
     "gcs_selftest_native_parts": (_i, [_i, _i, _i]),
     "gcs_device_cu_count": (_i, []),

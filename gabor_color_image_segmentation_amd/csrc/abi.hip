@@ -72,10 +72,9 @@ extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int 
     if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo)) return 0;
     return (size_t)B * lo.ntiles * lo.tile_bytes;
 }
-extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
-    GcsLayout lo;
-    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
-    return (size_t)B * lo.ntiles * KP_TP;
+extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {            // uint8 raster map [B][H][W], padded to 16 bytes
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return ((size_t)B * H * W + 15) / 16 * 16;
 }
 // Workgroups (= partial-sum rows) per image of one Lloyd pass. Sized to the machine: the pass
 // kernel runs 3 workgroups per CU, so B*parts aims at one full wave of 256*3 workgroups (a
@@ -86,9 +85,10 @@ extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {
 #define GCS_KP_SLOTS 768
 #endif
 extern "C" size_t gcs_kmeans_parts_per_image(int B, int H, int W) {
-    GcsLayout lo;
-    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
-    const size_t px = (size_t)lo.ntiles * KP_TP;
+    // from the shape alone (tiles without packed edge strips: an upper bound for every bank), so that the partial-sum
+    // buffer and the reduce calls need not know the bank
+    if (B <= 0 || H <= 0 || W <= 0 || gcs_tiles_upper(H, W) > 0x0fffffffLL) return 0;
+    const size_t px = (size_t)gcs_tiles_upper(H, W) * KP_TP;
     const size_t need = (px + 65535) / 65536;
     // small batches (B * parts would leave most of the 768 slots empty): down to 2 tiles per workgroup - one image then
     // runs on 313 workgroups instead of 78 and a pass takes a third of the time (it is latency-bound: 14 MB per image).

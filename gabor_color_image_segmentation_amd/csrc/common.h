@@ -30,21 +30,39 @@ static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles o
 
 // ------------------------------------------------------------------------ slab geometry
 // The feature slab keeps every pyramid level at its own resolution (SPEC.md §3). The image is cut into
-// 8x8-pixel BLOCKS, numbered in raster order (blk = by * bx_n + bx, bx_n = ceil(W/8)); a block owns its
-// 8x8 level-0 pixels and their parents: 4x4 level-1, 2x2 level-2 and 1 level-3 pixel. Four consecutive
-// blocks form a TILE = the 256 pixels one k-means workgroup step handles (one block per wave). A tile is
-// ONE contiguous run of bytes:
+// 8x8-pixel BLOCKS; a block owns 8x8 level-0 pixel SLOTS (iy, ix) and the slots of their parents: 4x4 level-1, 2x2 level-2
+// and 1 level-3 (the parent of slot (iy, ix) at level L is slot (iy >> L, ix >> L)). Four consecutive blocks form a TILE =
+// the 256 pixels one k-means workgroup step handles (one block per wave). A tile is ONE contiguous run of bytes:
 //     [level 0: D_0 planes x 256 u16][level 1: D_1 x 64][level 2: D_2 x 16][level 3: D_3 x 4]
-// (each level block padded to 16 bytes), pixel order inside a plane = (block in tile, row, column) of that
+// (each level block padded to 16 bytes), slot order inside a plane = (block in tile, slot row, slot column) of that
 // level's sub-block. Planes are in PHYSICAL order: level-major, then channel, then filter-in-level; logical
 // feature d = c*F + f (SPEC.md §3) with f = 2L*n_orient + fl. Values are stored offset-binary (x ^ 0x8080) so
-// that both bytes are signed MFMA digits. Labels use the same pixel order: [B][tile][256] uint8.
+// that both bytes are signed MFMA digits.
+//
+// Which pixel sits in which slot (round 4):
+//   MAIN blocks   bx_n x by_n blocks in raster order, block (by, bx) slot (iy, ix) = pixel (8 by + iy, 8 bx + ix).
+//   EDGE STRIPS   both sides of every BSD500 image are 8k + 1 pixels (481 x 321): with main blocks alone the last block
+//                 column and row would hold ONE pixel column / row each and 3.7 % of the bytes every Lloyd pass streams
+//                 would be padding. For banks of at most two pyramid levels, a right edge of 1 or 2 columns
+//                 (W mod 8 in {1, 2}) and a bottom edge of 1 or 2 rows are therefore packed into VIRTUAL blocks behind the
+//                 main ones: a strip is one level-1 parent wide, a virtual block holds 16 consecutive parents of it
+//                 (parent q = 4 (iy >> 1) + (ix >> 1) of the block's 4x4 parent slots) with their up to four pixels:
+//                   right strip, block v:  pixel (2 (16 v + q) + (iy & 1), Wm + (ix & 1)),  rows 0 .. H-1 (corner included)
+//                   bottom strip, block v: pixel (Hm + (iy & 1), 2 (16 v + q) + (ix & 1)),  columns 0 .. Wb-1
+//                 so the level-1 replication the kernels do (slot (iy, ix) -> parent slot (iy >> 1, ix >> 1)) holds
+//                 unchanged, and 481 x 321 takes 2 426 blocks (2 400 + 11 + 15) instead of 2 501. Deeper banks keep
+//                 main blocks only (a strip block's 8 level-2 parents do not fit a block's 2x2 level-2 slots).
 constexpr int GCS_LEVELS_MAX = 4;
 constexpr int KP_TP = 256;            // pixels per tile = threads per k-means workgroup
+constexpr int GCS_NO_STRIP = 1 << 29; // Wm / Hm of a layout without that strip: no coordinate reaches it
 
 struct GcsLayout {
     int H, W;                         // full-resolution image
-    int bx_n, by_n, nblk, ntiles;     // 8x8 blocks per row / column / image; tiles per image
+    int bx_n, by_n, nmain;            // MAIN 8x8 blocks per row / column / image
+    int nR, nB;                       // virtual blocks of the right / bottom edge strip (0: not packed)
+    int Wm, Hm;                       // first column of the right strip / first row of the bottom strip (GCS_NO_STRIP: none)
+    int Wb;                           // columns of the bottom strip: [0, Wb)
+    int nblk, ntiles;                 // blocks / tiles per image
     int n_levels, n_orient, F, D;     // pyramid levels, orientations, filters, features (3F)
     int FL[GCS_LEVELS_MAX];           // filters on level L
     int DL[GCS_LEVELS_MAX];           // planes on level L (3 * FL)
@@ -54,19 +72,34 @@ struct GcsLayout {
     int tile_bytes;
 };
 
+// Tiles per image when no edge strip is packed: an upper bound of every bank's tile count for the shape (sizes that
+// must not depend on the bank: partial-sum rows per image).
+static inline long long gcs_tiles_upper(int H, int W) {
+    return (((long long)(W + 7) / 8) * ((H + 7) / 8) + 3) / 4;
+}
+
 // Returns false when the shape is not representable.
 static inline bool gcs_make_layout(int H, int W, int n_scales, int n_orient, GcsLayout *lo) {
     if (H <= 0 || W <= 0 || n_scales < 1 || n_scales > 2 * GCS_LEVELS_MAX || n_orient < 1) return false;
     memset(lo, 0, sizeof *lo);
     lo->H = H;
     lo->W = W;
-    lo->bx_n = (W + 7) / 8;
-    lo->by_n = (H + 7) / 8;
-    const long long nblk = (long long)lo->bx_n * lo->by_n;
+    lo->n_levels = (n_scales + 1) / 2;
+    const bool may_pack = lo->n_levels <= 2 && H >= 8 && W >= 8;
+    const bool pack_r = may_pack && ((W & 7) == 1 || (W & 7) == 2);
+    const bool pack_b = may_pack && ((H & 7) == 1 || (H & 7) == 2);
+    lo->bx_n = pack_r ? W / 8 : (W + 7) / 8;
+    lo->by_n = pack_b ? H / 8 : (H + 7) / 8;
+    lo->Wm = pack_r ? 8 * lo->bx_n : GCS_NO_STRIP;
+    lo->Hm = pack_b ? 8 * lo->by_n : GCS_NO_STRIP;
+    lo->Wb = pack_r ? lo->Wm : W;
+    lo->nR = pack_r ? ((H + 1) / 2 + 15) / 16 : 0;
+    lo->nB = pack_b ? ((lo->Wb + 1) / 2 + 15) / 16 : 0;
+    const long long nmain = (long long)lo->bx_n * lo->by_n, nblk = nmain + lo->nR + lo->nB;
     if (nblk > 0x3fffffffLL) return false;
+    lo->nmain = (int)nmain;
     lo->nblk = (int)nblk;
     lo->ntiles = (lo->nblk + 3) / 4;
-    lo->n_levels = (n_scales + 1) / 2;
     lo->n_orient = n_orient;
     const long long F = (long long)n_scales * n_orient;
     if (F > 21845) return false;      // D = 3F must fit the uint16 plane indices used on the host side
@@ -90,6 +123,34 @@ static inline bool gcs_make_layout(int H, int W, int n_scales, int n_orient, Gcs
     return true;
 }
 
+// Pixel (y, x) -> its block and slot. The corner of two packed strips belongs to the right one.
+__host__ __device__ __forceinline__ void gcs_locate(const GcsLayout &lo, int y, int x, int &blk, int &iy, int &ix) {
+    if (x >= lo.Wm) {
+        const int R = y >> 1, q = R & 15;
+        blk = lo.nmain + (R >> 4);
+        iy = 2 * (q >> 2) + (y & 1);
+        ix = 2 * (q & 3) + (x & 1);
+    } else if (y >= lo.Hm) {
+        const int C = x >> 1, q = C & 15;
+        blk = lo.nmain + lo.nR + (C >> 4);
+        iy = 2 * (q >> 2) + (y & 1);
+        ix = 2 * (q & 3) + (x & 1);
+    } else {
+        blk = (y >> 3) * lo.bx_n + (x >> 3);
+        iy = y & 7;
+        ix = x & 7;
+    }
+}
+// Slot (iy, ix) of STRIP block blk (blk >= nmain) -> pixel; `xlim` = the first column that is not this strip's.
+__device__ __forceinline__ void gcs_strip_pixel(const GcsLayout &lo, int blk, int iy, int ix, int &y, int &x, int &xlim) {
+    const bool right = blk < lo.nmain + lo.nR;
+    const int v = blk - lo.nmain - (right ? 0 : lo.nR);
+    const int s = 32 * v + 8 * (iy >> 1) + 2 * (ix >> 1);
+    y = right ? s + (iy & 1) : lo.Hm + (iy & 1);
+    x = right ? lo.Wm + (ix & 1) : s + (ix & 1);
+    xlim = right ? lo.W : lo.Wb;
+}
+
 // physical plane -> (level, plane in level); logical feature <-> physical plane
 __host__ __device__ __forceinline__ int gcs_level_of_plane(const GcsLayout &lo, int r) {
     int L = 0;
@@ -111,15 +172,15 @@ __host__ __device__ __forceinline__ int gcs_plane_of_logical(const GcsLayout &lo
 }
 
 // Byte offset (from the slab base) of the value of physical plane r at FULL-resolution pixel (y, x) of image b:
-// the level-L parent (y >> L, x >> L) inside the pixel's block.
+// the level-L parent slot (iy >> L, ix >> L) inside the pixel's block.
 __device__ __forceinline__ size_t gcs_slab_offset(const GcsLayout &lo, int b, int r, int y, int x) {
     const int L = gcs_level_of_plane(lo, r);
-    const int blk = (y >> 3) * lo.bx_n + (x >> 3);
+    int blk, iy, ix;
+    gcs_locate(lo, y, x, blk, iy, ix);
     const int side = 8 >> L;                                          // sub-block side at level L
-    const int iy = (y & 7) >> L, ix = (x & 7) >> L;
     const int npl = KP_TP >> (2 * L);                                 // pixels per plane of a tile at level L
     return ((size_t)b * lo.ntiles + (blk >> 2)) * lo.tile_bytes + lo.off[L] +
-           ((size_t)(r - lo.row0[L]) * npl + (blk & 3) * side * side + iy * side + ix) * 2;
+           ((size_t)(r - lo.row0[L]) * npl + (blk & 3) * side * side + (iy >> L) * side + (ix >> L)) * 2;
 }
 
 // Partial sums of one Lloyd pass: [set][chunk of 16 elements][row][16] uint64, one row per k-means workgroup (sets = images

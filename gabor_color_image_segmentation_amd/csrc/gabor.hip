@@ -257,6 +257,13 @@ struct GaborLevel {
 struct GaborLevels {
     GaborLevel lv[GCS_LEVELS_MAX];
 };
+// Where the features go: the slab's block geometry (csrc/common.h) in level-0 pixels. Wm / Hm = GCS_NO_STRIP when the right /
+// bottom edge strip is not packed into virtual blocks (then every pixel sits in a main block).
+struct GaborSlab {
+    int bx_n, nmain, nR;     // main blocks per block row; main blocks per image; virtual blocks of the right strip
+    int Wm, Hm;              // first column of the right strip, first row of the bottom strip
+    int ntiles, tile_bytes;
+};
 
 // The bank of one level as an im2col GEMM on v_mfma_i32_32x32x32_i8 (round 3 layout).
 //   A rows  one 32-row tile = FOUR filters x {re_lo, re_hi, im_lo, im_hi} x TWO pixel shifts: row 8i + 4h + j is digit j of
@@ -285,8 +292,7 @@ constexpr int G_COPY = 3 * G_LROWS * G_LPITCH;      // bytes of one copy of a ti
 
 template <int MT, int GQ, int KS, int LVL, bool FAST>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
-    GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, int bx_n, int ntiles,
-    int tile_bytes) {
+    GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, GaborSlab S) {
     // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
     // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
     // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
@@ -464,21 +470,19 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         };
         auto store_block = [&]() {
             // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy. Level 0: one row of one 8x8 block = one 16-byte
-            // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels).
+            // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels). Pixels of
+            // a packed edge strip (csrc/common.h: banks of at most two levels) go to their virtual block instead.
             // compile-time geometry for single-level launches
             const int Lc = LVL >= 0 ? LVL : L, ssh = LVL >= 0 ? 3 - LVL : side_sh, nplc = LVL >= 0 ? (KP_TP >> (2 * (LVL >= 0 ? LVL : 0))) : npl;
             const int oy = y0 + st_trow, ox = x0 + 8 * li;
             if (oy < HL && ox < pitchL) {
-                const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
-                const int bx0 = ox >> ssh;
                 // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
-                // target block (tile of the block, block inside the tile, row inside the block, filter parity h), so that a
+                // target block (tile of the block, slot inside the tile, filter parity h), so that a
                 // store costs no vector address arithmetic (global_store with an SGPR base).
-                unsigned char *ubase = feats + (size_t)b * ntiles * tile_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
-                const unsigned row_off = (unsigned)(((iy << ssh) + h * nplc) * 2);
-                auto lane_off = [&](int p) -> unsigned {           // block bx0 + p, this lane's row inside it
-                    const int blk = by * bx_n + bx0 + p;
-                    return (unsigned)(blk >> 2) * (unsigned)tile_bytes + (unsigned)((blk & 3) << (2 * ssh)) * 2u + row_off;
+                unsigned char *ubase = feats + (size_t)b * S.ntiles * S.tile_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
+                // slot `slot` (in level-Lc pixels) of block blk, this lane's filter parity
+                auto slot_off = [&](int blk, int slot) -> unsigned {
+                    return (unsigned)(blk >> 2) * (unsigned)S.tile_bytes + (unsigned)((((blk & 3) << (2 * ssh)) + slot + h * nplc) * 2);
                 };
                 auto planes = [&](auto &&put) {
 #pragma unroll
@@ -493,40 +497,93 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                                 outp[mt][fp][3]);
                         }
                 };
-                if (Lc == 0) {
+                // tiles that touch a packed edge strip (the last tile column / row of a BSD image) take the general address
+                // computation; every other tile keeps the plain one (a wave-uniform branch: the strip code costs the common
+                // tile nothing - with per-lane selects in every tile the stage was 2 % slower)
+                const bool edge_tile = x0 + G_TW > (S.Wm >> Lc) || y0 + G_TH > (S.Hm >> Lc);
+                if (Lc == 0 && !edge_tile) {
                     // nontemporal: the slab (0.9 GB per 64 images) is read back only by the Lloyd passes; plain stores
                     // leave ~0.3 GB of it dirty in L2 / Infinity Cache and the first pass then shares HBM with their
                     // write-back (same-box A/B: first pass 0.219 -> 0.186 ms, step -2 %)
-                    const unsigned o0 = lane_off(0);
+                    const unsigned o0 = slot_off((oy >> 3) * S.bx_n + (ox >> 3), 8 * (oy & 7));
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
                     });
-                } else if (Lc == 1) {
-                    const unsigned o0 = lane_off(0), o1 = lane_off(1);
-                    const bool has1 = bx0 + 1 < bx_n;
+                } else if (Lc == 0) {
+                    if (ox >= S.Wm) {
+                        // right strip: this lane's first pixel pair (columns Wm, Wm + 1) of row oy = parent q of virtual block R >> 4
+                        const int R = oy >> 1, q = R & 15;
+                        const unsigned o0 = slot_off(S.nmain + (R >> 4), 8 * (2 * (q >> 2) + (oy & 1)) + 2 * (q & 3));
+                        planes([&](unsigned char *up, unsigned w0, unsigned, unsigned, unsigned) {
+                            __builtin_nontemporal_store((int)w0, reinterpret_cast<int *>(up + o0));
+                        });
+                    } else {
+                        // a row of a main block, or (bottom strip) the 8 pixels = 4 parents q0 .. q0 + 3 of a virtual block's
+                        // slot row: 16 contiguous bytes either way
+                        const int q0 = (ox >> 1) & 15;
+                        const bool bot = oy >= S.Hm;
+                        const int blk = bot ? S.nmain + S.nR + (ox >> 5) : (oy >> 3) * S.bx_n + (ox >> 3);
+                        const int row = bot ? 2 * (q0 >> 2) + (oy & 1) : oy & 7;
+                        const unsigned o0 = slot_off(blk, 8 * row);
+                        planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                            __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
+                        });
+                    }
+                } else if (Lc == 1 && !edge_tile) {
+                    const unsigned o0 = slot_off((oy >> 2) * S.bx_n + (ox >> 2), 4 * (oy & 3));
+                    const unsigned o1 = slot_off((oy >> 2) * S.bx_n + (ox >> 2) + 1, 4 * (oy & 3));
+                    const bool has1 = (ox >> 2) + 1 < S.bx_n;
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o0));
                         if (has1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o1));
                     });
+                } else if (Lc == 1) {
+                    // two pieces of four level-1 pixels X0 .. X0 + 3 (X0 = ox, ox + 4): a row of a main block's 4x4 parents, four
+                    // parents of the bottom strip (row Hm / 2), or - first pixel only - the right strip's parent (column Wm / 2)
+                    const int Wm1 = S.Wm >> 1, Hm1 = S.Hm >> 1;
+                    unsigned o[2];
+                    int kind[2];                      // 0: nothing, 1: 8 bytes, 2: the first pixel alone
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int X0 = ox + 4 * p;
+                        if (X0 >= Wm1) {
+                            kind[p] = X0 == Wm1 ? 2 : 0;
+                            o[p] = slot_off(S.nmain + (oy >> 4), oy & 15);
+                        } else if (oy >= Hm1) {
+                            kind[p] = 1;
+                            o[p] = slot_off(S.nmain + S.nR + (X0 >> 4), X0 & 15);
+                        } else {
+                            kind[p] = (X0 >> 2) < S.bx_n ? 1 : 0;
+                            o[p] = slot_off((oy >> 2) * S.bx_n + (X0 >> 2), 4 * (oy & 3));
+                        }
+                    }
+                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        if (kind[0] == 1) __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o[0]));
+                        else if (kind[0] == 2) *reinterpret_cast<uint16_t *>(up + o[0]) = (uint16_t)w0;
+                        if (kind[1] == 1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o[1]));
+                        else if (kind[1] == 2) *reinterpret_cast<uint16_t *>(up + o[1]) = (uint16_t)w2;
+                    });
                 } else if (Lc == 2) {
+                    const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1), bx0 = ox >> ssh;
                     unsigned o[4];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) o[p] = lane_off(p);
+                    for (int p = 0; p < 4; ++p) o[p] = slot_off(by * S.bx_n + bx0 + p, iy << ssh);
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         const unsigned w[4] = {w0, w1, w2, w3};
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
-                            if (bx0 + p < bx_n) *reinterpret_cast<unsigned *>(up + o[p]) = w[p];
+                            if (bx0 + p < S.bx_n) *reinterpret_cast<unsigned *>(up + o[p]) = w[p];
                     });
                 } else {
+                    const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1), bx0 = ox >> ssh;
                     unsigned o[8];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) o[p] = lane_off(p);
+                    for (int p = 0; p < 8; ++p) o[p] = slot_off(by * S.bx_n + bx0 + p, iy << ssh);
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         const unsigned w[4] = {w0, w1, w2, w3};
 #pragma unroll
                         for (int p = 0; p < 8; ++p)
-                            if (bx0 + p < bx_n)
+                            if (bx0 + p < S.bx_n)
                                 *reinterpret_cast<uint16_t *>(up + o[p]) = (uint16_t)(w[p >> 1] >> (16 * (p & 1)));
                     });
                 }
@@ -787,12 +844,13 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 G.lv[i].tile_end = 0x7fffffff;
             }
             const int total_tiles = (int)total_ll;
+            const GaborSlab slab{lo.bx_n, lo.nmain, lo.nR, lo.Wm, lo.Hm, lo.ntiles, lo.tile_bytes};
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
             const int slots = gcs_cu_count() * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
-                       reinterpret_cast<unsigned char *>(feats), total_tiles, lo.bx_n, lo.ntiles, lo.tile_bytes)
+                       reinterpret_cast<unsigned char *>(feats), total_tiles, slab)
             // single launches of level 0 / level 1 (every bank of at most two levels) compile that level's store path alone
 #define GCS_GABOR_LAUNCH3(MT_, GQ_, KS_, FA_)                                       \
     do {                                                                            \

@@ -8,7 +8,9 @@
 //   kmeans_assign_kernel     generic pass for D >= 208: exact integer argmin via fp32 byte-digit FMAs (all partial
 //                            sums < 2^24, hence exact), LDS-replicated u32 accumulators.
 //   kmeans_reduce_kernel     element-major partial sums -> int64 sums (+ the centroid update when single-rank).
-//   kmeans_finalize / init / features_gather / labels_widen / labels_raster: small helpers.
+//   kmeans_finalize / init / features_gather / labels_widen: small helpers.
+// Label maps leave every pass in RASTER order ([B][H][W] uint8 or int32): which slot of which block holds a pixel
+// (csrc/common.h: main blocks and packed edge strips) is the passes' own business.
 // Nothing here allocates, frees or synchronises; every entry point enqueues on the caller's stream.
 #include "common.h"
 #include <type_traits>
@@ -169,10 +171,10 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(
             }
             lab[p] = bj;
         }
-        if (labels) {   // label slab: same pixel order as the feature slab (tile, block in tile, row, column)
-            const int blk = (y >> 3) * lo.bx_n + (x >> 3);
-            uint8_t *lp = labels + ((size_t)b * lo.ntiles + (blk >> 2)) * KP_TP + (blk & 3) * 64 + (y & 7) * 8 + (x & 7);
-            *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(lab[0] | (lab[1] << 8));
+        if (labels) {   // uint8 raster map [B][H][W]
+            uint8_t *lp = labels + ((size_t)b * H + y) * W + x;
+            lp[0] = (uint8_t)lab[0];
+            if (x + 1 < W) lp[1] = (uint8_t)lab[1];
         }
         // accumulate (second pass over this thread's planes; L2-resident)
         const bool rows_ok = partials && y >= row_lo && y < row_hi;
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                                           : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
-    int parts, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels, uint64_t *__restrict__ partials,
-    void *__restrict__ raster, int raster_u8) {
+    int parts, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials, void *__restrict__ raster,
+    int raster_u8) {
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
     constexpr int NTHR = 64 * WAVES;                         // threads per workgroup
     constexpr int NT_OWN = WAVES == 8 ? (KP_NT + 1) / 2 : KP_NT;   // update plane tiles a wave accumulates
@@ -260,9 +262,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
 
-    // either output may be absent (host contract): labels == NULL on the passes whose assignment nobody reads (every
+    // either output may be absent (host contract): raster == NULL on the passes whose assignment nobody reads (every
     // pass but the last), partials == NULL on the last pass, whose sums nobody reads (no update phase, no fold)
-    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;    // (raster: see the assign phase)
+    const bool do_acc = partials != nullptr;                 // (raster: see the assign phase)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = tid >> 6;                                // 0 .. WAVES-1
     const int wave = wid & 3;                                // the block of the tile this wave works on
@@ -280,7 +282,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     const int nlist = ntiles * nimg;
     const size_t img0 = per_image ? (size_t)b * ntiles : 0;               // first tile of the list in the slab
     const unsigned char *fb = feats + img0 * lo.tile_bytes;               // each tile one contiguous run
-    uint8_t *lb = labels + img0 * KP_TP;
 
     // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16 in PHYSICAL
     //      plane order, stored offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D.
@@ -545,13 +546,22 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
             const int bj = (int)((pb < best ? pb : best) & 15);
             if (h == 0) {
-                const int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7);
-                const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
+                // which pixel this slot holds (csrc/common.h): a main block's, or - rarely - an edge strip's
+                int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7), xlim = lo.W;
+                if (blk >= lo.nmain) {           // 26 of the 2 426 blocks of a BSD image
+                    // the slot coordinates are re-derived from an opaque copy of the lane number: derived from `n` they are
+                    // loop invariants, hipcc keeps them in VGPRs across the tile loop and the pass (168 VGPRs for three
+                    // workgroups per CU) spills
+                    int no = n;
+                    asm volatile("" : "+v"(no));
+                    gcs_strip_pixel(lo, blk, 4 * sub + (no >> 3), no & 7, y, x, xlim);
+                }
+                const bool inimg = blk < lo.nblk && y < lo.H && x < xlim;
+                const bool valid = inimg && y >= row_lo && y < row_hi;      // votes in the sums (halo rows do not)
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
-                if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
-                // the label map itself, raster order [B][H][W] (gcs_kmeans_assign_raster: the last pass; no separate
-                // slab -> raster kernel): eight lanes cover one row of the block, 32 (int32) or 8 (uint8) contiguous bytes
-                if (raster && valid) {
+                // the label map itself, raster order [B][H][W] (the last pass): in a main block eight lanes cover one row
+                // of the block, 32 (int32) or 8 (uint8) contiguous bytes
+                if (raster && inimg) {
                     const size_t o = ((size_t)(per_image ? b : tile / ntiles) * lo.H + y) * lo.W + x;
                     if (raster_u8) static_cast<uint8_t *>(raster)[o] = (uint8_t)bj;
                     else static_cast<int32_t *>(raster)[o] = bj;
@@ -676,8 +686,8 @@ __device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i 
 template <int NL, int NT, int NST, int MINB>
 __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
-    int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint8_t *__restrict__ labels,
-    uint64_t *__restrict__ partials, void *__restrict__ raster, int raster_u8) {
+    int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials,
+    void *__restrict__ raster, int raster_u8) {
     constexpr int TILE_B = (NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END) + 512;   // + room for the over-reads of unused columns
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[TILE_B];
     __shared__ __attribute__((aligned(16))) int2 s_part[4][NL - 1][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     __shared__ int s_cnt[4][4][16];                                     // [wave][pixel group][cluster] voting pixels
     __shared__ long long s_nj[16];
 
-    const bool do_lab = labels != nullptr, do_acc = partials != nullptr;
+    const bool do_acc = partials != nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grid (B, parts): workgroups are dispatched part-major, so the parts_eff * B working ones are the first to start
     const int b = blockIdx.x, part = blockIdx.y, nb = (int)gridDim.x;
@@ -700,7 +710,6 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const int nlist = ntiles * nimg;
     const size_t img0 = per_image ? (size_t)b * ntiles : 0;
     const unsigned char *fb = feats + img0 * lo.tile_bytes;
-    uint8_t *lb = labels + img0 * KP_TP;
     auto prow = [&](int i) -> size_t { return partial_index(per_image, b, part, parts, nb, i, K * D1); };
     if (!working) {                                              // a zero partial row, nothing else
         if (do_acc)
@@ -907,11 +916,16 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
             const int bj = (int)((pb < best ? pb : best) & 15);
             if (h == 0) {
-                const int y = 8 * by + yi, x = 8 * bx + xi;
-                const bool valid = blk < lo.nblk && y >= row_lo && y < row_hi && x < lo.W;
+                int y = 8 * by + yi, x = 8 * bx + xi, xlim = lo.W;          // see kmeans_pass_mfma_kernel
+                if (NL <= 2 && blk >= lo.nmain) {               // (deeper banks have main blocks only)
+                    int no = n;
+                    asm volatile("" : "+v"(no));
+                    gcs_strip_pixel(lo, blk, 4 * sub + (no >> 3), no & 7, y, x, xlim);
+                }
+                const bool inimg = blk < lo.nblk && y < lo.H && x < xlim;
+                const bool valid = inimg && y >= row_lo && y < row_hi;
                 s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
-                if (do_lab) lb[(size_t)tile * KP_TP + pl] = (uint8_t)bj;
-                if (raster && valid) {                        // raster label map (see kmeans_pass_mfma_kernel)
+                if (raster && inimg) {                        // raster label map (see kmeans_pass_mfma_kernel)
                     const size_t o = ((size_t)(per_image ? b : tile / ntiles) * lo.H + y) * lo.W + x;
                     if (raster_u8) static_cast<uint8_t *>(raster)[o] = (uint8_t)bj;
                     else static_cast<int32_t *>(raster)[o] = bj;
@@ -1103,15 +1117,13 @@ static int native_parts_eff(int B, int parts, long long px_image) {
 }
 // Test hook (host only): the working workgroups per image the native pass would use, 0 for a bad shape.
 extern "C" int gcs_selftest_native_parts(int B, int H, int W) {
-    GcsLayout lo;
-    if (B <= 0 || !gcs_make_layout(H, W, 1, 1, &lo)) return 0;
-    return native_parts_eff(B, (int)gcs_kmeans_parts_per_image(B, H, W), (long long)lo.ntiles * KP_TP);
+    if (B <= 0 || H <= 0 || W <= 0 || gcs_tiles_upper(H, W) > 0x3fffffffLL) return 0;
+    return native_parts_eff(B, (int)gcs_kmeans_parts_per_image(B, H, W), gcs_tiles_upper(H, W) * KP_TP);
 }
 
 extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream);
-extern "C" int gcs_labels_raster_u8(const uint8_t *labels, int B, int H, int W, uint8_t *out, gcs_stream_t stream);
 
-// One Lloyd pass, whatever it emits: label slab, partial sums, raster label map (any subset, not none).
+// One Lloyd pass, whatever it emits: uint8 label map, partial sums, raster label map (any subset, not none).
 static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H, int W, int n_scales, int n_orient, int k,
                       int n_sets, int row_lo, int row_hi, int reverse, uint8_t *labels, uint64_t *partials, void *raster,
                       int raster_u8, gcs_stream_t stream) {
@@ -1129,10 +1141,14 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
     const int D = lo.D;
     if (D < 16 * KP_DSTEPS_WIDE) { // matrix-core pass (every BASELINE bank: 4x6 -> D = 72, 8x8 -> D = 192)
         const int parts = (int)gcs_kmeans_parts_per_image(B, H, W);
+        // the matrix-core passes have ONE label output, in raster order: the caller's raster map, or its uint8 label map
+        // (assign_accumulate with labels: every pixel of the image is labelled, halo rows of a row window included)
+        void *lab_out = raster ? raster : static_cast<void *>(labels);
+        const int lab_u8 = raster ? raster_u8 : 1;
 #define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
-                       reverse ? 1 : 0, row_lo, row_hi, labels, partials, raster, raster_u8)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8)
 #define GCS_KP_LAUNCH(KT_, NST_, DS_) GCS_KP_LAUNCHW(KT_, NST_, DS_, 4)
         const int nchunk = lo.tile_bytes / 16;
         const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
@@ -1158,7 +1174,7 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
     hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
-                       reverse ? 1 : 0, row_lo, row_hi, labels, partials, raster, raster_u8)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8)
                 if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
                 else if (lo.n_levels == 3) GCS_NV_LAUNCH(3);
                 else GCS_NV_LAUNCH(4);
@@ -1178,8 +1194,10 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         GCS_CHECK_LAUNCH("gcs_kmeans_assign_accumulate");
         return GCS_OK;
     }
-    if (raster && !labels)
-        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_raster: feature vectors of 208 or more planes need the scratch label slab");
+    // generic pass: uint8 raster labels only. A uint8 raster map is written directly, an int32 one through the scratch map.
+    if (raster && raster_u8) labels = static_cast<uint8_t *>(raster);
+    else if (raster && !labels)
+        return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_raster: feature vectors of 208 or more planes need the scratch label map for int32 output");
     int rc = GCS_EINVAL;
     switch (k) { // generic VALU pass for wider feature vectors
 #define GCS_CASE(KK) \
@@ -1190,10 +1208,8 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         GCS_CASE(9) GCS_CASE(10) GCS_CASE(11) GCS_CASE(12) GCS_CASE(13) GCS_CASE(14) GCS_CASE(15) GCS_CASE(16)
 #undef GCS_CASE
     }
-    if (rc != GCS_OK || !raster) return rc;
-    // the generic pass writes the slab only: one more launch turns it into the raster map
-    return raster_u8 ? gcs_labels_raster_u8(labels, B, H, W, static_cast<uint8_t *>(raster), stream)
-                     : gcs_labels_widen(labels, B, H, W, static_cast<int32_t *>(raster), stream);
+    if (rc != GCS_OK || !raster || raster_u8) return rc;
+    return gcs_labels_widen(labels, B, H, W, static_cast<int32_t *>(raster), stream);   // uint8 -> int32: one more launch
 }
 
 extern "C" int gcs_kmeans_assign_accumulate(const uint16_t *feats, const uint16_t *cent, int B, int H, int W,
@@ -1347,51 +1363,27 @@ extern "C" int gcs_kmeans_finalize(const int64_t *sums, int n_sets, int k, int D
     return GCS_OK;
 }
 
-// ----------------------------------------------------------------------------- label slab -> raster
-// Block = 64 x 4 threads: four image rows per block; a thread converts 4 labels of one row (half a block row: one
-// aligned dword of the slab) per step of 64 dwords.
-template <typename OUT>
-__global__ __launch_bounds__(256) void labels_raster_kernel(const uint8_t *__restrict__ labels, int H, int W, int bx_n,
-                                                            int ntiles, int rows, OUT *__restrict__ out) {
-    const int byr = blockIdx.x * 4 + threadIdx.y;     // b*H + y
-    if (byr >= rows) return;
-    const int b = byr / H, y = byr - b * H;
-    const uint8_t *img = labels + (size_t)b * ntiles * KP_TP;
-    OUT *dst = out + (size_t)byr * W;
-    for (int x4 = threadIdx.x; 4 * x4 < W; x4 += 64) {
-        const int blk = (y >> 3) * bx_n + (x4 >> 1);
-        const unsigned v = *reinterpret_cast<const unsigned *>(img + (size_t)(blk >> 2) * KP_TP + (blk & 3) * 64 +
-                                                               (y & 7) * 8 + (x4 & 1) * 4);
-        if (sizeof(OUT) == 4 && 4 * x4 + 3 < W) {        // one 16-byte store (any 4-byte alignment: rows of W ints start anywhere)
-            typedef int __attribute__((ext_vector_type(4), aligned(4))) v4i_a4;
-            *reinterpret_cast<v4i_a4 *>(dst + 4 * x4) =
-                v4i_a4{(int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24)};
-        } else if (sizeof(OUT) == 1 && 4 * x4 + 3 < W) {
-            typedef unsigned __attribute__((aligned(1))) u32_a1;
-            *reinterpret_cast<u32_a1 *>(dst + 4 * x4) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * x4 + e < W) dst[4 * x4 + e] = (OUT)((v >> (8 * e)) & 255u);
-        }
+// ----------------------------------------------------------------------------- uint8 label map -> int32
+__global__ __launch_bounds__(256) void labels_widen_kernel(const uint8_t *__restrict__ labels, size_t n, int32_t *__restrict__ out) {
+    // four labels per thread where the dword is whole (the map starts on an allocation boundary: aligned)
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(labels + i4);
+        typedef int __attribute__((ext_vector_type(4), aligned(4))) v4i_a4;
+        *reinterpret_cast<v4i_a4 *>(out + i4) = v4i_a4{(int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24)};
+    } else {
+        for (size_t i = i4; i < n; ++i) out[i] = labels[i];
     }
 }
 
-template <typename OUT>
-static int labels_raster(const uint8_t *labels, int B, int H, int W, OUT *out, hipStream_t stream, const char *who) {
-    if (!labels || !out) return gcs_fail(GCS_EINVAL, who);
-    GcsLayout lo;
-    if (B <= 0 || (long long)B * H > 0x7fffffffLL || !gcs_make_layout(H, W, 1, 1, &lo)) return gcs_fail(GCS_EINVAL, who);
-    const int rows = B * H;
-    hipLaunchKernelGGL(labels_raster_kernel<OUT>, dim3((rows + 3) / 4), dim3(64, 4), 0, stream, labels, H, W, lo.bx_n,
-                       lo.ntiles, rows, out);
-    GCS_CHECK_LAUNCH(who);
-    return GCS_OK;
-}
-
 extern "C" int gcs_labels_widen(const uint8_t *labels, int B, int H, int W, int32_t *out, gcs_stream_t stream) {
-    return labels_raster<int32_t>(labels, B, H, W, out, stream, "gcs_labels_widen: bad argument");
-}
-extern "C" int gcs_labels_raster_u8(const uint8_t *labels, int B, int H, int W, uint8_t *out, gcs_stream_t stream) {
-    return labels_raster<uint8_t>(labels, B, H, W, out, stream, "gcs_labels_raster_u8: bad argument");
+    if (!labels || !out || B <= 0 || H <= 0 || W <= 0) return gcs_fail(GCS_EINVAL, "gcs_labels_widen: bad argument");
+    if ((reinterpret_cast<uintptr_t>(labels) & 3) || (reinterpret_cast<uintptr_t>(out) & 3))
+        return gcs_fail(GCS_EINVAL, "gcs_labels_widen: pointers must be 4-byte aligned");
+    const size_t n = (size_t)B * H * W;
+    const size_t blocks = (n / 4 + 1 + 255) / 256;
+    if (blocks > 0x7fffffffull) return gcs_fail(GCS_EINVAL, "gcs_labels_widen: map too large for one launch");
+    hipLaunchKernelGGL(labels_widen_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, labels, n, out);
+    GCS_CHECK_LAUNCH("gcs_labels_widen");
+    return GCS_OK;
 }

@@ -229,11 +229,6 @@ class HipOps:
         _lib.check(self.lib.gcs_labels_widen(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
                    "gcs_labels_widen")
 
-    @_on_device
-    def labels_raster_u8(self, labels, b, h, w, out):
-        _lib.check(self.lib.gcs_labels_raster_u8(labels.data_ptr(), b, h, w, out.data_ptr(), self._stream()),
-                   "gcs_labels_raster_u8")
-
     # centroid / sums tensors are ordinary torch tensors so torch.distributed can move them
     def new_centroids(self, n_sets, k):
         return self.torch.zeros((n_sets, k, self.bank.n_features), dtype=self.torch.int16, device=self.device)

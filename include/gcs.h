@@ -34,7 +34,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 15
+#define GCS_ABI_VERSION 16
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
@@ -63,9 +63,11 @@ size_t gcs_bank_bias_count(int n_scales, int n_orient);
 int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ksize, int8_t *packed, int32_t *bias);
 
 /* Feature slab: every pyramid level at its own resolution, tile-major (a tile = four 8x8-pixel blocks with
- * their level-1..3 parents, one contiguous run; see csrc/common.h), uint16 stored offset-binary (x ^ 0x8080:
- * both bytes are signed MFMA digits). Opaque to callers; gcs_features_unpack gives the canonical
- * [B][D][H][W] uint16 tensor of SPEC.md §3. Label slab: uint8 in the same pixel order. */
+ * their level-1..3 parents, one contiguous run; edge strips of one or two pixel columns / rows - both sides of a BSD500
+ * image are 8k + 1 pixels - are packed into virtual blocks for banks of at most two levels; see csrc/common.h), uint16
+ * stored offset-binary (x ^ 0x8080: both bytes are signed MFMA digits). Opaque to callers; gcs_features_unpack gives the
+ * canonical [B][D][H][W] uint16 tensor of SPEC.md §3. "Label slab": a uint8 label map in RASTER order, [B][H][W]
+ * (gcs_label_slab_bytes = B*H*W rounded up to 16). */
 size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient);
 size_t gcs_label_slab_bytes(int B, int H, int W);
 /* uint64 partial sums written by one assign pass: one row of k * (D+1) values per k-means workgroup, stored in chunks
@@ -110,7 +112,8 @@ int gcs_features_gather(const uint16_t *feats_dev, int B, int H, int W, int n_sc
  * Only rows [row_lo, row_hi) of each image vote in the sums (whole image: 0, H); halo rows of
  * a row-sharded image are labelled but do not vote. `reverse` != 0 sweeps the slab back to front:
  * alternate it from pass to pass so that each pass starts on what the previous one left in the
- * Infinity Cache (results do not depend on it). labels_dev: label slab; partials_dev:
+ * Infinity Cache (results do not depend on it). labels_dev: uint8 [B][H][W] label map (every pixel of every image is
+ * labelled, rows outside the voting window included); partials_dev:
  * gcs_kmeans_partial_bytes() bytes, fully overwritten (no zeroing needed). D <= 207 (every BASELINE bank) runs on
  * the matrix cores, wider feature vectors on a generic VALU pass; k <= GCS_K_MAX. The same n_sets must be passed
  * to the reduce call that follows (it selects the partial layout).
@@ -123,9 +126,9 @@ int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *cent
 
 /* The LAST Lloyd pass in one launch: assignment only (SPEC.md §4; the schedule's last pass has no update) with the label map
  * written straight in raster order, out_dev [B][H][W] int32 (out_u8 == 0: what metrics.py:43-51 consumes) or uint8
- * (out_u8 != 0). Same result as gcs_kmeans_assign_accumulate(labels, NULL) followed by gcs_labels_widen /
- * gcs_labels_raster_u8. scratch_labels_dev: a label slab (gcs_label_slab_bytes) that is needed, and then also filled, only
- * for feature vectors of 208 or more planes (the generic pass); may be NULL otherwise. Whole images only (no row window). */
+ * (out_u8 != 0). Same result as gcs_kmeans_assign_accumulate(labels, NULL) (followed by gcs_labels_widen for int32).
+ * scratch_labels_dev: a uint8 label map (gcs_label_slab_bytes) that is needed, and then also filled, only for int32 output of
+ * feature vectors of 208 or more planes (the generic pass); may be NULL otherwise. Whole images only (no row window). */
 int gcs_kmeans_assign_raster(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B, int H, int W, int n_scales,
                              int n_orient, int k, int n_sets, int reverse, void *out_dev, int out_u8,
                              uint8_t *scratch_labels_dev, gcs_stream_t stream);
@@ -146,13 +149,9 @@ int gcs_kmeans_reduce_finalize(const uint64_t *partials_dev, int B, int H, int W
                                int n_sets, int64_t *sums_dev, uint16_t *centroids_dev,
                                gcs_stream_t stream);
 
-/* Label slab -> int32 [B][H][W] (the dtype handed to metrics.py:43). */
+/* uint8 label map [B][H][W] -> int32 [B][H][W] (the dtype handed to metrics.py:43). Both pointers 4-byte aligned. */
 int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *out_dev,
                      gcs_stream_t stream);
-/* Label slab -> uint8 [B][H][W]: a quarter of the bytes for the device-to-host copy of the slot's host path
- * (script.py:30 returns a host array); the host widens it (metrics.py:43 casts to int anyway). */
-int gcs_labels_raster_u8(const uint8_t *labels_dev, int B, int H, int W, uint8_t *out_dev,
-                         gcs_stream_t stream);
 
 /* Test hook: counts in *bad_dev (uint32, device) the 4096-value chunks of [0, n_max] on which the kernels' 7-instruction
  * exact integer square root and its biased form in the epilogue (SPEC.md §3: n <= 2 * 32767^2 < 2^31, guaranteed by the

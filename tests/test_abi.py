@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 15
+    assert lib.gcs_abi_version() == 16
 
 
 def test_no_torch_types_in_the_abi():
@@ -31,15 +31,21 @@ def test_no_torch_types_in_the_abi():
 
 
 def test_geometry(lib):
-    """Pyramid slab (csrc/common.h): 8x8 blocks, four per tile; level L keeps 1/4^L of the pixels."""
-    blocks = 61 * 41                                            # ceil(481/8) x ceil(321/8)
+    """Pyramid slab (csrc/common.h): 8x8 blocks, four per tile; level L keeps 1/4^L of the pixels. Banks of at most two
+    levels pack the one-pixel edge strips of a BSD image (481 = 8*60 + 1, 321 = 8*40 + 1) into virtual blocks of 16 level-1
+    parents: 60 x 40 main blocks + 11 (right strip: 161 parent rows, corner included) + 15 (bottom strip: 240 parent columns)."""
+    blocks = 61 * 41                                            # ceil(481/8) x ceil(321/8): deep banks, main blocks only
     tiles = (blocks + 3) // 4
+    packed_tiles = (60 * 40 + 11 + 15 + 3) // 4                 # 607 instead of 626 tiles: 0.6 % padding instead of 3.7 %
     tile_bytes = 36 * 256 * 2 + 36 * 64 * 2                     # 4x6 bank: 12 filters x 3 channels on levels 0 and 1
-    assert lib.gcs_feature_slab_bytes(64, 321, 481, 4, 6) == 64 * tiles * tile_bytes
+    assert lib.gcs_feature_slab_bytes(64, 321, 481, 4, 6) == 64 * packed_tiles * tile_bytes
+    assert lib.gcs_feature_slab_bytes(64, 481, 321, 4, 6) == 64 * ((60 * 40 + 16 + 10 + 3) // 4) * tile_bytes   # portrait: 241 / 160 parents
+    assert lib.gcs_feature_slab_bytes(1, 322, 482, 2, 3) == ((60 * 40 + 11 + 15 + 3) // 4) * 18 * 256 * 2       # two-pixel strips pack too
+    assert lib.gcs_feature_slab_bytes(1, 323, 480, 2, 3) == ((60 * 41 + 3) // 4) * 18 * 256 * 2                 # a 3-row edge does not
     assert lib.gcs_feature_slab_bytes(1, 321, 481, 8, 8) == tiles * 48 * (256 + 64 + 16 + 4) * 2
     assert lib.gcs_feature_slab_bytes(1, 321, 481, 7, 1) == tiles * (6 * 512 + 6 * 128 + 6 * 32 + 32)   # 3 planes x 4 px x 2 B = 24 -> 32
     assert lib.gcs_feature_slab_bytes(1, 8, 8, 1, 1) == 3 * 512
-    assert lib.gcs_label_slab_bytes(2, 321, 481) == 2 * tiles * 256
+    assert lib.gcs_label_slab_bytes(2, 321, 481) == -(-2 * 321 * 481 // 16) * 16      # uint8 raster map
     assert lib.gcs_bank_packed_bytes(4, 6) == 6 * 8 * 64 * 16          # 12 filters per level -> 3 row tiles of 4 filters each
     assert lib.gcs_bank_packed_bytes(1, 1) == 8 * 64 * 16 and lib.gcs_bank_packed_bytes(8, 8) == 16 * 8 * 64 * 16
     assert lib.gcs_bank_bias_count(4, 6) == 24 and lib.gcs_bank_bias_count(3, 9) == 20 + 12
@@ -138,7 +144,6 @@ def test_device_entry_points_validate_before_launching(lib):
     assert lib.gcs_kmeans_reduce_finalize(one, 2, 16, 16, 72, 8, 3, None, one, None) == 1     # n_sets not in {1,B}
     assert lib.gcs_labels_widen(one, 1, 0, 16, one, None) == 1
     assert lib.gcs_features_unpack(one, 1, 16, 16, 0, 6, one, None) == 1
-    assert lib.gcs_labels_raster_u8(one, 1, 16, 0, one, None) == 1
     assert lib.gcs_selftest_isqrt(10, None, None) == 1
     assert lib.gcs_boundary_counts(one, one, 0, 16, 16, one, one, None) == 1
     assert lib.gcs_connected_regions(one, 0, 16, 16, one, one, None) == 1

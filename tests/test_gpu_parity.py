@@ -62,6 +62,56 @@ def test_features_extreme_pixels(torch_cuda):
         assert np.array_equal(got[b], so.gabor_features(imgs[b], tapq, shift, 6))
 
 
+@pytest.mark.parametrize("h,w", [(321, 481), (481, 321), (33, 41), (34, 42), (33, 40), (40, 41), (41, 58), (42, 57), (9, 10),
+                                 (17, 8), (8, 18), (161, 241), (65, 130), (35, 43)])
+@pytest.mark.parametrize("ns", [1, 2, 4])
+def test_packed_edge_strips_features_and_labels(torch_cuda, h, w, ns):
+    """Round-4 slab layout (csrc/common.h): edges of one or two pixel columns / rows (both sides of every BSD image are
+    8k + 1) live in virtual blocks of 16 level-1 parents behind the main 8x8 blocks, for banks of one and two pyramid
+    levels. Every combination of packed / unpacked right and bottom edges, both BSD orientations, strips shorter than one
+    virtual block and strips that end inside one: features (through gcs_features_unpack) and labels (both codebook modes,
+    int32 and uint8 raster maps, a row window) equal the C oracle's, bit for bit."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    from oracle import c_oracle as co
+    torch = torch_cuda
+    b = 2 if h * w > 50000 else 3
+    imgs = _synth(b, h, w, seed=100 + h + w)
+    seg = Segmenter(n_scales=ns, n_orient=3 if ns != 4 else 6, k=5, n_iter=3)
+    bank = seg.bank
+    d_imgs = torch.from_numpy(imgs).cuda()
+    got = seg.features_device(d_imgs).cpu().numpy().view(np.uint16)
+    for i in range(b):
+        ref = co.gabor_features(imgs[i], bank.tapq, bank.shift, bank.n_orient)
+        bad = np.argwhere(got[i] != ref)
+        assert bad.size == 0, f"image {i}: {len(bad)} feature mismatches, first (d, y, x) {bad[:4].tolist()}"
+    for mode in ("per_image", "global"):
+        want = co.segment_batch(imgs, bank.tapq, bank.shift, bank.n_orient, k=5, n_iter=3, mode=mode)
+        lab = seg.segment_device(d_imgs, mode=mode).cpu().numpy()
+        assert np.array_equal(lab, want), (mode, np.argwhere(lab != want)[:4].tolist())
+    assert np.array_equal(seg.segment_batch(imgs, out_dtype=np.uint8), co.segment_batch(
+        imgs, bank.tapq, bank.shift, bank.n_orient, k=5, n_iter=3, mode="per_image"))
+    # a Lloyd pass with a row window writes a uint8 label for EVERY pixel (rows outside the window do not vote)
+    ws = seg._tail_workspace(b, h, w, "global")
+    seg.ops.gabor_features(d_imgs, ws["feats"])
+    seg.ops.kmeans_init(ws["feats"], b, h, w, 5, 1, ws["cent"])
+    lo_, hi_ = h // 4, h - h // 5
+    seg.ops.assign_accumulate(ws["feats"], ws["cent"], b, h, w, 5, 1, ws["labels"], ws["partials"], rows=(lo_, hi_))
+    seg.ops.reduce(ws["partials"], b, h, w, 5, 1, ws["sums"])
+    lab8 = ws["labels"][:b * h * w].view(b, h, w).cpu().numpy()
+    cent = ws["cent"].cpu().numpy().view(np.uint16)[0].astype(np.int64)
+    feats = np.stack([co.gabor_features(im, bank.tapq, bank.shift, bank.n_orient) for im in imgs]).astype(np.int64)
+    x = feats.reshape(b, feats.shape[1], -1).transpose(0, 2, 1)                         # (b, P, D)
+    ref_lab = np.stack([so.kmeans_assign(x[i], cent) for i in range(b)]).reshape(b, h, w)
+    assert np.array_equal(lab8, ref_lab)
+    sums = ws["sums"].cpu().numpy()[0]
+    vote = np.zeros((h, w), bool)
+    vote[lo_:hi_] = True
+    for j in range(5):
+        m = (ref_lab == j) & vote[None]
+        assert sums[j, -1] == m.sum()
+        assert np.array_equal(sums[j, :-1], feats.transpose(0, 2, 3, 1)[m].sum(axis=0))
+
+
 @pytest.mark.parametrize("k,n_iter", [(8, 10), (3, 4), (16, 3), (1, 2), (5, 1)])
 def test_segment_labels_bit_exact(torch_cuda, k, n_iter):
     from gabor_color_image_segmentation_amd import Segmenter

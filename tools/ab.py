@@ -25,10 +25,14 @@ H, W = map(int, args.size.split("x"))
 B = args.batch
 imgs = torch.from_numpy(synthetic_shard(0, B, H, W)).cuda()
 segs = {}
+import ctypes
 for spec in args.libs:
     name, path = spec.split("=", 1)
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(path)
+    # an older build may be compared as long as the entry points used here kept their signatures (ABI 15 -> 16 only dropped
+    # gcs_labels_raster_u8 and turned the label slab into a raster map)
+    _lib.ABI_VERSION = ctypes.CDLL(_lib.LIB_PATH).gcs_abi_version()
     segs[name] = Segmenter(n_scales=ns, n_orient=no)
 n_sets = B if args.mode == "per_image" else 1
 
