@@ -250,18 +250,21 @@ struct GaborLevel {
     const int8_t *planes;    // padded planes [B][3][Hp][Wp]
     const int8_t *apack;     // packed taps of this launch's row tiles
     const int32_t *bias;
-    int HL, Hp, Wp, pitchL, tiles_x, tiles_per_image;
+    // The tile list covers the level's MAIN region, rows [0, HLm) x columns [0, pitchLm): the whole level, or - when the
+    // slab packs edge strips (csrc/common.h) - the level without them (gabor_strip_kernel computes those). The region is cut
+    // into HALF tiles of 32 x 32 pixels, htx per row, hcount per image; a workgroup's 64 x 32 tile is any two consecutive
+    // half tiles of one image (tiles_per_image = ceil(hcount / 2)), so a region 15 half tiles wide (480 pixels) costs 7.5
+    // tiles per tile row, not 8.
+    int HLm, Hp, Wp, pitchLm, htx, hcount, tiles_per_image;
     int tile_end;            // end of this level's tiles in the launch's tile list
     int L, offL;
 };
 struct GaborLevels {
     GaborLevel lv[GCS_LEVELS_MAX];
 };
-// Where the features go: the slab's block geometry (csrc/common.h) in level-0 pixels. Wm / Hm = GCS_NO_STRIP when the right /
-// bottom edge strip is not packed into virtual blocks (then every pixel sits in a main block).
+// Where the MFMA kernel's features go: the slab's main blocks (csrc/common.h).
 struct GaborSlab {
-    int bx_n, nmain, nR;     // main blocks per block row; main blocks per image; virtual blocks of the right strip
-    int Wm, Hm;              // first column of the right strip, first row of the bottom strip
+    int bx_n;                // main blocks per block row
     int ntiles, tile_bytes;
 };
 
@@ -316,12 +319,25 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     auto pick = [&](int l) -> GaborLevel { return l == 0 ? G.lv[0] : l == 1 ? G.lv[1] : l == 2 ? G.lv[2] : G.lv[3]; };
     static_assert(GCS_LEVELS_MAX == 4, "level_of / pick enumerate four levels");
 
+    // the two half tiles (rows y, columns x of their first pixel) of tile `rem` of an image; an absent second half (odd
+    // half-tile count) is placed below the region: it is staged from the first half's window and stores nothing
+    auto halves_of = [&](int rem, int htx, int hcount, int &ya, int &xa, int &yb, int &xb) {
+        const int q0 = 2 * rem, hy = q0 / htx, hx = q0 - hy * htx;
+        ya = hy * G_TH;
+        xa = hx * (G_TW / 2);
+        const bool wrap = hx + 1 == htx;
+        yb = q0 + 1 < hcount ? (wrap ? ya + G_TH : ya) : (1 << 28);
+        xb = wrap ? 0 : xa + G_TW / 2;
+    };
     auto stage_tile = [&](int tile, int lvl, int buf) {
         const GaborLevel v = pick(lvl);
         const int t_ = tile - (lvl ? pick(lvl - 1).tile_end : 0);
         const int b_ = t_ / v.tiles_per_image, rem = t_ % v.tiles_per_image;
-        const int y0_ = (rem / v.tiles_x) * G_TH, x0_ = (rem % v.tiles_x) * G_TW;
-        const int8_t *src0 = v.planes + ((size_t)b_ * 3 * v.Hp + y0_) * v.Wp + x0_;
+        int ya, xa, yb, xb;
+        halves_of(rem, v.htx, v.hcount, ya, xa, yb, xb);
+        if (yb >= (1 << 28)) { yb = ya; xb = xa; }
+        const int8_t *srcA = v.planes + ((size_t)b_ * 3 * v.Hp + ya) * v.Wp + xa;
+        const int8_t *srcB = v.planes + ((size_t)b_ * 3 * v.Hp + yb) * v.Wp + xb;
 #pragma unroll
         for (int k = 0; k < (NCHUNK + 255) / 256; ++k) {
             const int i = tid + 256 * k;
@@ -329,8 +345,10 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                 const int copy = i >= NCHUNK1, i1 = i - copy * NCHUNK1;
                 const int ch16 = i1 % (G_LPITCH / 16), rc = i1 / (G_LPITCH / 16);
                 const int row = rc % G_LROWS, c = rc / G_LROWS;
-                // the second copy is the same window read two bytes further right (LDS-DMA takes any source alignment)
-                const int8_t *g = src0 + ((size_t)c * v.Hp + row) * v.Wp + 16 * ch16 + 2 * copy;
+                // an LDS row = the 48-byte windows of the two half tiles side by side (32 pixels + 14 of halo + the second
+                // copy's 2); the second copy is the same window read two bytes further right (LDS-DMA takes any source alignment)
+                const bool right = ch16 >= G_LPITCH / 32;
+                const int8_t *g = (right ? srcB : srcA) + ((size_t)c * v.Hp + row) * v.Wp + 16 * (ch16 - (right ? G_LPITCH / 32 : 0)) + 2 * copy;
                 // LDS destination: wave-uniform base (this wave's first chunk) in M0 + lane * 16. Issued as asm: hipcc models
                 // the builtin as a store to "some LDS" and then drains vmcnt - the DMA AND every feature store still in
                 // flight - in front of the next LDS read of the loop, i.e. at the top of every 4-row block (round 2 and the
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
 
     const int r = lane & 31, h = lane >> 5;
     const int li = r & 7, lyy = r >> 3;
+    const int lcol = 8 * li + (li >= 4 ? G_LPITCH / 2 - G_TW / 2 : 0);   // first window byte of the lane's pixels in its half's 48-byte LDS window
 
     int k256 = 256, k65536 = 65536;
     asm volatile("" : "+s"(k256), "+s"(k65536));      // opaque multipliers: keep v_mad_i32_i24 / v_mad_u32_u24, not shifts
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     // ---- per level: the whole A operand lives in registers (MT x KS lane-linear 16-byte fragments) with the biases
     v4i afr[MT][KS];
     int bias_v[MT][2];
-    int HL = 0, pitchL = 0, tiles_x = 1, tiles_per_image = 1, tile0 = 0, L = 0, offL = 0;
+    int HL = 0, pitchL = 0, htx = 1, hcount = 1, tiles_per_image = 1, tile0 = 0, L = 0, offL = 0;   // (HL, pitchL: the main region's)
     int side_sh = 3, npl = KP_TP;          // slab geometry of the level (csrc/common.h): sub-block side 8 >> L, pixels per plane of a tile
     auto enter_level = [&](int lvl) {
         const GaborLevel v = pick(lvl);
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int fp = 0; fp < 2; ++fp) bias_v[mt][fp] = v.bias[4 * mt + 2 * fp + h];
-        HL = v.HL; pitchL = v.pitchL; tiles_x = v.tiles_x; tiles_per_image = v.tiles_per_image;
+        HL = v.HLm; pitchL = v.pitchLm; htx = v.htx; hcount = v.hcount; tiles_per_image = v.tiles_per_image;
         tile0 = lvl ? pick(lvl - 1).tile_end : 0;
         L = LVL >= 0 ? LVL : v.L;
         offL = v.offL;
@@ -396,15 +415,18 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
       }
       const int tl = tile - tile0;
       const int b = tl / tiles_per_image, trem = tl % tiles_per_image;
-      const int y0 = (trem / tiles_x) * G_TH, x0 = (trem % tiles_x) * G_TW;
+      int y0a, x0a, y0b, x0b;                                       // the tile's two half tiles: lanes li < 4 / li >= 4
+      halves_of(trem, htx, hcount, y0a, x0a, y0b, x0b);
+      const int y0 = li < 4 ? y0a : y0b, x0 = (li < 4 ? x0a : x0b) - (li < 4 ? 0 : G_TW / 2);   // per lane; x0 + 8 li = the lane's first pixel
       // The wave's work in this tile: 4-row blocks (channel c, row block rb), a software pipeline over ALL of them: every
       // block is 4 MT chains of KS MFMAs (pixel pair pp, tile mt); chain t shares its scheduling region with the epilogue of
       // chain t-1 - for the first chain of a block that is the LAST chain of the previous block, whose stores follow it - and
       // the fragments of the next pixel pair (for the last pair: of the next block) are read from LDS one pair ahead. Round 2
       // and the first round-3 build drained the pipeline at every block: a region of MFMAs alone, a region of VALU alone and
       // an exposed LDS read per block.
-      const bool rows1 = y0 + wave * 8 + 4 < HL;                    // both row blocks of this wave hold image rows
-      const int nblk = y0 + wave * 8 < HL ? (rows1 ? 6 : 3) : 0;    // waves wholly below the image skip the work, not the barrier
+      const int ytop = (y0a < y0b ? y0a : y0b) + wave * 8;          // this wave's first row in the upper of the two half tiles
+      const bool rows1 = ytop + 4 < HL;                             // both row blocks of this wave hold region rows (in some half)
+      const int nblk = ytop < HL ? (rows1 ? 6 : 3) : 0;             // waves wholly below the region skip the work, not the barrier
       if (nblk) {
         unsigned outp[MT][2][4];           // [tile][filter pair][pixel pair]: two uint16 magnitudes each
         v16i acc[2];
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         // fragment kk of pixel pair pp = 2 qq + copy of block (wc, wtrow): 16 bytes of copy `copy` at byte 8 li + 4 qq of
         // tap row 2 kk + h (this half-wave's parity)
         auto load_fragment = [&](int kk, int wc, int wtrow, int copy, int qq) -> v4i {
-            const int8_t *rp = &s_tile[buf][copy][wc][wtrow + 2 * kk + h][8 * li];
+            const int8_t *rp = &s_tile[buf][copy][wc][wtrow + 2 * kk + h][lcol];
             if (qq == 0) {
                 const v2i lo = *reinterpret_cast<const v2i *>(rp), hi = *reinterpret_cast<const v2i *>(rp + 8);
                 return v4i{lo[0], lo[1], hi[0], hi[1]};
@@ -469,20 +491,23 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             }
         };
         auto store_block = [&]() {
-            // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy. Level 0: one row of one 8x8 block = one 16-byte
-            // store; level L: 2^L pieces of 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels). Pixels of
-            // a packed edge strip (csrc/common.h: banks of at most two levels) go to their virtual block instead.
+            // 8 consecutive level pixels x = x0 + 8*li .. +7 of row oy of the MAIN region (packed edge strips are not in the
+            // tile list: gabor_strip_kernel). Level 0: one row of one 8x8 block = one 16-byte store; level L: 2^L pieces of
+            // 8 >> L pixels, one per block (a block holds (8 >> L)^2 level-L pixels).
             // compile-time geometry for single-level launches
             const int Lc = LVL >= 0 ? LVL : L, ssh = LVL >= 0 ? 3 - LVL : side_sh, nplc = LVL >= 0 ? (KP_TP >> (2 * (LVL >= 0 ? LVL : 0))) : npl;
             const int oy = y0 + st_trow, ox = x0 + 8 * li;
             if (oy < HL && ox < pitchL) {
+                const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
+                const int bx0 = ox >> ssh;
                 // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
-                // target block (tile of the block, slot inside the tile, filter parity h), so that a
+                // target block (tile of the block, block inside the tile, row inside the block, filter parity h), so that a
                 // store costs no vector address arithmetic (global_store with an SGPR base).
                 unsigned char *ubase = feats + (size_t)b * S.ntiles * S.tile_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
-                // slot `slot` (in level-Lc pixels) of block blk, this lane's filter parity
-                auto slot_off = [&](int blk, int slot) -> unsigned {
-                    return (unsigned)(blk >> 2) * (unsigned)S.tile_bytes + (unsigned)((((blk & 3) << (2 * ssh)) + slot + h * nplc) * 2);
+                const unsigned row_off = (unsigned)(((iy << ssh) + h * nplc) * 2);
+                auto lane_off = [&](int p) -> unsigned {           // block bx0 + p, this lane's row inside it
+                    const int blk = by * S.bx_n + bx0 + p;
+                    return (unsigned)(blk >> 2) * (unsigned)S.tile_bytes + (unsigned)((blk & 3) << (2 * ssh)) * 2u + row_off;
                 };
                 auto planes = [&](auto &&put) {
 #pragma unroll
@@ -497,77 +522,25 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                                 outp[mt][fp][3]);
                         }
                 };
-                // tiles that touch a packed edge strip (the last tile column / row of a BSD image) take the general address
-                // computation; every other tile keeps the plain one (a wave-uniform branch: the strip code costs the common
-                // tile nothing - with per-lane selects in every tile the stage was 2 % slower)
-                const bool edge_tile = x0 + G_TW > (S.Wm >> Lc) || y0 + G_TH > (S.Hm >> Lc);
-                if (Lc == 0 && !edge_tile) {
+                if (Lc == 0) {
                     // nontemporal: the slab (0.9 GB per 64 images) is read back only by the Lloyd passes; plain stores
                     // leave ~0.3 GB of it dirty in L2 / Infinity Cache and the first pass then shares HBM with their
                     // write-back (same-box A/B: first pass 0.219 -> 0.186 ms, step -2 %)
-                    const unsigned o0 = slot_off((oy >> 3) * S.bx_n + (ox >> 3), 8 * (oy & 7));
+                    const unsigned o0 = lane_off(0);
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
                     });
-                } else if (Lc == 0) {
-                    if (ox >= S.Wm) {
-                        // right strip: this lane's first pixel pair (columns Wm, Wm + 1) of row oy = parent q of virtual block R >> 4
-                        const int R = oy >> 1, q = R & 15;
-                        const unsigned o0 = slot_off(S.nmain + (R >> 4), 8 * (2 * (q >> 2) + (oy & 1)) + 2 * (q & 3));
-                        planes([&](unsigned char *up, unsigned w0, unsigned, unsigned, unsigned) {
-                            __builtin_nontemporal_store((int)w0, reinterpret_cast<int *>(up + o0));
-                        });
-                    } else {
-                        // a row of a main block, or (bottom strip) the 8 pixels = 4 parents q0 .. q0 + 3 of a virtual block's
-                        // slot row: 16 contiguous bytes either way
-                        const int q0 = (ox >> 1) & 15;
-                        const bool bot = oy >= S.Hm;
-                        const int blk = bot ? S.nmain + S.nR + (ox >> 5) : (oy >> 3) * S.bx_n + (ox >> 3);
-                        const int row = bot ? 2 * (q0 >> 2) + (oy & 1) : oy & 7;
-                        const unsigned o0 = slot_off(blk, 8 * row);
-                        planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
-                            __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
-                        });
-                    }
-                } else if (Lc == 1 && !edge_tile) {
-                    const unsigned o0 = slot_off((oy >> 2) * S.bx_n + (ox >> 2), 4 * (oy & 3));
-                    const unsigned o1 = slot_off((oy >> 2) * S.bx_n + (ox >> 2) + 1, 4 * (oy & 3));
-                    const bool has1 = (ox >> 2) + 1 < S.bx_n;
+                } else if (Lc == 1) {
+                    const unsigned o0 = lane_off(0), o1 = lane_off(1);
+                    const bool has1 = bx0 + 1 < S.bx_n;
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o0));
                         if (has1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o1));
                     });
-                } else if (Lc == 1) {
-                    // two pieces of four level-1 pixels X0 .. X0 + 3 (X0 = ox, ox + 4): a row of a main block's 4x4 parents, four
-                    // parents of the bottom strip (row Hm / 2), or - first pixel only - the right strip's parent (column Wm / 2)
-                    const int Wm1 = S.Wm >> 1, Hm1 = S.Hm >> 1;
-                    unsigned o[2];
-                    int kind[2];                      // 0: nothing, 1: 8 bytes, 2: the first pixel alone
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int X0 = ox + 4 * p;
-                        if (X0 >= Wm1) {
-                            kind[p] = X0 == Wm1 ? 2 : 0;
-                            o[p] = slot_off(S.nmain + (oy >> 4), oy & 15);
-                        } else if (oy >= Hm1) {
-                            kind[p] = 1;
-                            o[p] = slot_off(S.nmain + S.nR + (X0 >> 4), X0 & 15);
-                        } else {
-                            kind[p] = (X0 >> 2) < S.bx_n ? 1 : 0;
-                            o[p] = slot_off((oy >> 2) * S.bx_n + (X0 >> 2), 4 * (oy & 3));
-                        }
-                    }
-                    planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
-                        if (kind[0] == 1) __builtin_nontemporal_store(v2i{(int)w0, (int)w1}, reinterpret_cast<v2i *>(up + o[0]));
-                        else if (kind[0] == 2) *reinterpret_cast<uint16_t *>(up + o[0]) = (uint16_t)w0;
-                        if (kind[1] == 1) __builtin_nontemporal_store(v2i{(int)w2, (int)w3}, reinterpret_cast<v2i *>(up + o[1]));
-                        else if (kind[1] == 2) *reinterpret_cast<uint16_t *>(up + o[1]) = (uint16_t)w2;
-                    });
                 } else if (Lc == 2) {
-                    const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1), bx0 = ox >> ssh;
                     unsigned o[4];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) o[p] = slot_off(by * S.bx_n + bx0 + p, iy << ssh);
+                    for (int p = 0; p < 4; ++p) o[p] = lane_off(p);
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         const unsigned w[4] = {w0, w1, w2, w3};
 #pragma unroll
@@ -575,10 +548,9 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                             if (bx0 + p < S.bx_n) *reinterpret_cast<unsigned *>(up + o[p]) = w[p];
                     });
                 } else {
-                    const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1), bx0 = ox >> ssh;
                     unsigned o[8];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) o[p] = slot_off(by * S.bx_n + bx0 + p, iy << ssh);
+                    for (int p = 0; p < 8; ++p) o[p] = lane_off(p);
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         const unsigned w[4] = {w0, w1, w2, w3};
 #pragma unroll
@@ -638,6 +610,109 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed in LDS
       __syncthreads();   // next tile landed (vmcnt drained) and this buffer is free to refill
+    }
+}
+
+// ---------------------------------------------------------------------------- edge strips
+// The packed edge strips of the slab (csrc/common.h: right edge of one or two pixel columns, bottom edge of one or two rows,
+// banks of at most two levels - every BSD500 image, both levels): 802 + 402 of a 481 x 321 image's pixels. Inside the tile
+// grid of gabor_mfma_kernel they cost a whole extra tile column and tile row per level (84 + 22 instead of 75 + 20 tile
+// times per image); here they are 87 small tasks per image. One wave = one task = 32 pixel PAIRS of one channel: for the
+// column strip the pairs (WmL, WmL + 1) of 32 consecutive rows, for a row strip 64 consecutive pixels of the row. The window
+// fragments come straight from the padded planes in global memory (any byte alignment; the planes were written a moment
+// ago and sit in L2 / Infinity Cache), the A fragments from the packed bank, same K binding and accumulator layout as
+// gabor_mfma_kernel; general (any shift) epilogue; every magnitude is stored as one uint16 at gcs_slab_offset.
+struct StripLevel {
+    const int8_t *planes;    // padded planes [B][3][Hp][Wp] of the level
+    const int8_t *apack;     // the level's packed taps (all its row tiles)
+    const int32_t *bias;
+    int Hp, Wp, HL, WL;
+    int col_x, nseg_col;     // column strip: level column col_x (and col_x + 1), rows [0, HL) in nseg_col segments of 32 rows
+    int row_y, row_n;        // row strips: level rows [row_y, row_y + row_n) ...
+    int row_w, nseg_row;     // ... columns [0, row_w), nseg_row segments of 64 pixels per row
+    int task_end;            // end of this level's tasks in an image's task list (task = (segment, channel))
+    int FL, MT, row0;        // filters of the level, its row tiles, its first physical plane
+    int L;                   // the pyramid level
+};
+struct StripArgs {
+    StripLevel lv[2];
+    int n_levels, tasks_per_image;
+};
+typedef int __attribute__((ext_vector_type(4), aligned(1))) v4i_a1;
+
+template <int KS>
+__global__ __launch_bounds__(256) void gabor_strip_kernel(StripArgs A, GcsLayout lo, int shift, unsigned char *__restrict__ feats,
+                                                          int total_tasks) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);     // wave-uniform
+    if (task >= total_tasks) return;
+    const int b = task / A.tasks_per_image;
+    int t = task - b * A.tasks_per_image;
+    const int lvl = A.n_levels > 1 && t >= A.lv[0].task_end ? 1 : 0;
+    const StripLevel v = lvl ? A.lv[1] : A.lv[0];
+    if (lvl) t -= A.lv[0].task_end;
+    const int seg = t / 3, c = t - 3 * seg;
+    const int n = lane & 31, h = lane >> 5;
+    int y, x, xlim;                                           // this lane's pixel pair (y, x), (y, x + 1); columns below xlim exist
+    bool ok;
+    if (seg < v.nseg_col) {
+        y = 32 * seg + n;
+        x = v.col_x;
+        xlim = v.WL;
+        ok = y < v.HL;
+    } else {
+        const int s2 = seg - v.nseg_col, rr = s2 / v.nseg_row, sg = s2 - rr * v.nseg_row;
+        y = v.row_y + rr;
+        x = 64 * sg + 2 * n;
+        xlim = v.row_w;
+        ok = x < v.row_w;
+    }
+    // window rows y + 2 kk + h of the padded plane (plane row r = level row r - 7), 16 columns from plane column x; lanes
+    // without a pixel read a valid window and store nothing
+    const int8_t *wp = v.planes + ((size_t)(b * 3 + c) * v.Hp + (ok ? y : 0) + h) * v.Wp + (ok ? x : 0);
+    v4i win[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) win[kk] = *reinterpret_cast<const v4i_a1 *>(wp + (size_t)2 * kk * v.Wp);
+    // Where the pair's magnitudes go: the slot of pixel (y, x) in the channel's first plane of this level; filter fl sits
+    // fl planes further (same tile, same slot), the pair's second pixel in the next slot (x is even: slots ix, ix + 1 of a
+    // main or strip block; level-1 parents q, q + 1 of one row of four): one 4-byte store per filter
+    const size_t base = gcs_slab_offset(lo, b, v.row0 + c * v.FL, (ok ? y : 0) << v.L, (ok ? x : 0) << v.L);
+    const int plane_bytes = (KP_TP >> (2 * v.L)) * 2;
+    const bool both = x + 1 < xlim;
+    const v4i *ap = reinterpret_cast<const v4i *>(v.apack) + lane;
+    v4i a_cur[KS], a_nxt[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a_cur[kk] = ap[(size_t)kk * 64];
+    for (int mt = 0; mt < v.MT; ++mt) {
+        const int mn = mt + 1 < v.MT ? mt + 1 : mt;               // the next row tile's fragments travel during this one's work
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a_nxt[kk] = ap[((size_t)mn * 8 + kk) * 64];
+        v16i acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[kk], win[kk], acc, 0, 0, 0);
+        // accumulator quad i = 2 fp + sx = {re_lo, re_hi, im_lo, im_hi} of filter 4 mt + 2 fp + h at pixel x + sx
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {
+            const int fl = 4 * mt + 2 * fp + h;
+            const int bias = v.bias[fl < v.FL ? fl : 0];
+            unsigned mag[2];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const int i = 2 * fp + sx;
+                const int v_re = acc[4 * i + 1] * 256 + acc[4 * i + 0] + bias, v_im = acc[4 * i + 3] * 256 + acc[4 * i + 2];
+                const int a_re = v_re >> shift, a_im = v_im >> shift;
+                mag[sx] = isqrt31((unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im));
+            }
+            if (ok && fl < v.FL) {
+                unsigned char *dst = feats + base + (size_t)fl * plane_bytes;
+                if (both) *reinterpret_cast<unsigned *>(dst) = (mag[0] | (mag[1] << 16)) ^ 0x80808080u;
+                else *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(mag[0] ^ 0x8080u);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a_cur[kk] = a_nxt[kk];
     }
 }
 
@@ -726,6 +801,11 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     if ((size_t)W * 6 + 16 > 60 * 1024) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: W too large for the pyramid row buffer");
     unsigned char *wsb = static_cast<unsigned char *>(workspace);
     const dim3 block(256);
+    // Main region of level L (what gabor_mfma_kernel's tile list covers) and whether gabor_strip_kernel has work
+    const bool pack_r = lo.Wm != GCS_NO_STRIP, pack_b = lo.Hm != GCS_NO_STRIP, strips = pack_r || pack_b;
+    auto region_h = [&](int L) { return pack_b ? lo.Hm >> L : ws.HL[L]; };
+    auto region_w = [&](int L) { return pack_r ? lo.Wm >> L : ws.WL[L]; };
+    auto half_tiles = [&](int L) { return (long long)((region_w(L) + G_TW / 2 - 1) / (G_TW / 2)) * ((region_h(L) + G_TH - 1) / G_TH); };
     // Two-level bank (the default): level 1 only needs the input images, so its pre-pass and its MFMA launch run on a side
     // stream forked from the caller's stream here and joined back before this call returns to it: beside the level-0
     // pre-pass and in the tail of the level-0 MFMA launch (same-box A/B, three runs: stage 0.552 -> 0.530, 0.565 -> 0.542,
@@ -799,8 +879,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     // the fused list: level 1's tiles then run beside level 0's instead of in a launch of their own behind them (one image:
     // the two launches take 19 us each, one after the other; the slot is called once per image, script.py:22-30).
     long long tiles_all = 0;
-    for (int L = 0; L < lo.n_levels; ++L)
-        tiles_all += (long long)B * ((ws.WL[L] + G_TW - 1) / G_TW) * ((ws.HL[L] + G_TH - 1) / G_TH);
+    for (int L = 0; L < lo.n_levels; ++L) tiles_all += (long long)B * ((half_tiles(L) + 1) / 2);
     const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
     auto launch_group = [&](int L0, int &L1) -> int {
         L1 = L0 + 1;
@@ -827,12 +906,13 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 v.planes = reinterpret_cast<const int8_t *>(wsb + ws.plane_off[L]);
                 v.apack = packed + (size_t)(mt_base[L] + mt0) * 8 * 64 * 16;
                 v.bias = bias + (size_t)(mt_base[L] + mt0) * 4;
-                v.HL = ws.HL[L];
+                v.HLm = region_h(L);
                 v.Hp = ws.Hp[L];
                 v.Wp = ws.Wp[L];
-                v.pitchL = round_up(ws.WL[L], 8);
-                v.tiles_x = (ws.WL[L] + G_TW - 1) / G_TW;
-                v.tiles_per_image = v.tiles_x * ((ws.HL[L] + G_TH - 1) / G_TH);
+                v.pitchLm = pack_r ? region_w(L) : round_up(ws.WL[L], 8);
+                v.htx = (region_w(L) + G_TW / 2 - 1) / (G_TW / 2);
+                v.hcount = (int)half_tiles(L);
+                v.tiles_per_image = (v.hcount + 1) / 2;
                 total_ll += (long long)v.tiles_per_image * B;
                 if (total_ll > 0x3fffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
                 v.tile_end = (int)total_ll;
@@ -844,7 +924,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 G.lv[i].tile_end = 0x7fffffff;
             }
             const int total_tiles = (int)total_ll;
-            const GaborSlab slab{lo.bx_n, lo.nmain, lo.nR, lo.Wm, lo.Hm, lo.ntiles, lo.tile_bytes};
+            const GaborSlab slab{lo.bx_n, lo.ntiles, lo.tile_bytes};
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
             const int slots = gcs_cu_count() * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots);
@@ -885,8 +965,55 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         }
         return GCS_OK;
     };
-    for (int L0 = 0, L1 = 0; L0 < lo.n_levels; L0 = L1)
+    // The packed edge strips (57 + 30 tasks of a few microseconds per BSD image), one small launch per level on the level's
+    // stream IN FRONT of its MFMA launch: level 0's right behind the plane pre-pass, while the chip is still empty (a launch
+    // behind the MFMA kernels cost 27 us at the end of the stage; reserving four CUs for it beside level 0 held level 1 back:
+    // profiles/r4_notes.md), level 1's on the side stream in the tail of level 0 like level 1 itself.
+    auto launch_strips = [&](int L0s, int L1s) -> int {
+        StripArgs A{};
+        A.n_levels = L1s - L0s;
+        int tasks = 0;
+        for (int L = L0s; L < L1s; ++L) {
+            StripLevel &v = A.lv[L - L0s];
+            v.planes = reinterpret_cast<const int8_t *>(wsb + ws.plane_off[L]);
+            v.apack = packed + (size_t)mt_base[L] * 8 * 64 * 16;
+            v.bias = bias + (size_t)mt_base[L] * 4;
+            v.Hp = ws.Hp[L]; v.Wp = ws.Wp[L]; v.HL = ws.HL[L]; v.WL = ws.WL[L];
+            v.col_x = pack_r ? lo.Wm >> L : 0;
+            v.nseg_col = pack_r ? (ws.HL[L] + 31) / 32 : 0;
+            v.row_y = pack_b ? lo.Hm >> L : 0;
+            v.row_n = pack_b ? ws.HL[L] - (lo.Hm >> L) : 0;
+            v.row_w = pack_r ? lo.Wm >> L : ws.WL[L];
+            v.nseg_row = (v.row_w + 63) / 64;
+            tasks += 3 * (v.nseg_col + v.row_n * v.nseg_row);
+            v.task_end = tasks;
+            v.FL = lo.FL[L]; v.MT = mtiles(lo.FL[L]); v.row0 = lo.row0[L]; v.L = L;
+        }
+        if (A.n_levels == 1) A.lv[1] = A.lv[0];
+        A.tasks_per_image = tasks;
+        const long long total = (long long)tasks * B;
+        if (total > 0x3fffffffLL) { (void)join(); return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many strip tasks"); }
+        hipStream_t ss = GCS_STREAM_OF(L0s);
+        const dim3 sgrid((unsigned)((total + 3) / 4));
+        if (ksize <= 13)
+            hipLaunchKernelGGL((gabor_strip_kernel<7>), sgrid, block, 0, ss, A, lo, shift, reinterpret_cast<unsigned char *>(feats), (int)total);
+        else
+            hipLaunchKernelGGL((gabor_strip_kernel<8>), sgrid, block, 0, ss, A, lo, shift, reinterpret_cast<unsigned char *>(feats), (int)total);
+        GCS_GABOR_CHECK("gcs_gabor_features(strips)");
+        return GCS_OK;
+    };
+    for (int L0 = 0, L1 = 0; L0 < lo.n_levels; L0 = L1) {
+        // (a fused list - L1 > L0 + 1 - joins the side stream first: every level's planes are then ready on `stream`)
+        int Lend = L0 + 1;
+        if (lo.n_levels > 2 || fuse_small)
+            while (Lend < lo.n_levels && lo.FL[Lend] == lo.FL[L0]) ++Lend;
+        if (strips) {
+            if (L0 == 0 && Lend > 1)
+                if (int rc = join()) return rc;
+            if (int rc = launch_strips(L0, Lend < 2 ? Lend : 2)) return rc;
+        }
         if (int rc = launch_group(L0, L1)) return rc;
+    }
     if (int rc = join()) return rc;
 #undef GCS_GABOR_CHECK
 #undef GCS_STREAM_OF

@@ -705,10 +705,15 @@ class Segmenter:
                 # block recycled, whenever a later call needs a larger one)
                 scratch = self.ops.gabor_scratch(b, h, w)
 
+                # (the closure must not capture `self`: the entry lives in self._graphs, and a Segmenter inside a reference
+                # cycle is freed - with its graphs, streams, pinned and device buffers - only when the cyclic collector
+                # happens to run, not when the last user drops it)
+                ops, k, n_iter, debug = self.ops, self.k, self.n_iter, self.debug
+
                 def step():
-                    self.ops.gabor_features(dev_in, ws["feats"], scratch=scratch)
-                    lloyd(self.ops, ws["feats"], b, h, w, self.k, self.n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
-                          ws["sums"], raster=dev_out, debug=self.debug)
+                    ops.gabor_features(dev_in, ws["feats"], scratch=scratch)
+                    lloyd(ops, ws["feats"], b, h, w, k, n_iter, mode, ws["labels"], ws["partials"], ws["cent"],
+                          ws["sums"], raster=dev_out, debug=debug)
                 dev_in.zero_()
                 step()                                     # eager once: first-use work (side-stream creation) outside the capture
                 torch.cuda.synchronize(dev)

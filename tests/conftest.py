@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("GCS_DEBUG_ABORT"):
+        # diagnostics for a native abort(): a SIGABRT handler that prints the raising thread's native backtrace
+        # (tools/dbg/abrt_bt.c; run with -p no:faulthandler) and the objects each cyclic collection frees
+        import ctypes
+        import gc
+        import torch  # noqa: F401  (load the HIP runtime first: whoever installs handlers at load time goes before us)
+        ctypes.CDLL(os.path.join(ROOT, "tools", "dbg", "abrt_bt.so")).abrt_bt_install()
+        gc.set_debug(gc.DEBUG_COLLECTABLE)
 
 
 @pytest.fixture(scope="session")

@@ -178,6 +178,29 @@ def test_a_replayed_graph_never_writes_through_a_recycled_scratch_block(torch_cu
         assert bool((c == 0x5A).all())
 
 
+def test_a_dropped_segmenter_is_released_at_once(torch_cuda):
+    """A plan owns device slabs, pinned buffers, streams, worker threads and captured graphs: dropping the last reference
+    must release them by reference counting, not whenever the cyclic collector next runs (the graph entries used to hold a
+    closure over the Segmenter: a cycle; a test session then piled up dozens of dead plans)."""
+    import gc
+    import weakref
+    from gabor_color_image_segmentation_amd import Segmenter
+    seg = Segmenter(n_iter=2)
+    small, batch = _synth(1, 40, 64, seed=3), _synth(20, 250, 330, seed=4)
+    seg.segment_batch(small)                                   # graph path
+    seg.segment_batch(batch)                                   # chunked upload path
+    assert len(list(seg.segment_stream([batch, batch]))) == 2  # three-stream pipeline
+    assert len(list(seg.segment_images(list(small) * 3, batch=2))) == 3
+    gc.collect()
+    gc.disable()
+    try:
+        ref = weakref.ref(seg)
+        del seg
+        assert ref() is None, gc.get_referrers(ref())
+    finally:
+        gc.enable()
+
+
 def test_segment_stream_equals_segment_batch(torch_cuda):
     """The pipelined host API (three streams, depth + 1 buffer slots): seven batches through segment_stream give, in order,
     exactly what segment_batch gives for each - both label dtypes, both codebook modes, a depth larger than the input."""
