@@ -454,6 +454,17 @@ def main():
         extra["config5_halo_bytes_per_edge"] = halo_rows(bank.n_levels, bank.ksize) * 2048 * 3
         del big, out5
 
+    if world == 1 and not args.no_other_mode:
+        # the batched GPU scorer on the 24 packed BSD500 val images (device-resident label maps, ground truth
+        # from the 500-id pack) and the segment + score loop of examples/bsd_eval.py --val; images per second, never `value`
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import scoring_rate
+            log("scoring throughput (24 BSD val images)")
+            extra["scoring"] = scoring_rate.measure(seg, reps=3)
+        except FileNotFoundError as e:             # the golden pack is part of the repo; a stripped copy simply skips this
+            extra["scoring"] = {"skipped": str(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ref, cpu = cpu_baseline(B, args.k, args.n_iter, args.mode)

@@ -230,6 +230,19 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
+// The slab is read once per pass and is far larger than every cache: the tile loads carry the nontemporal hint
+// (global_load_dwordx4 ... nt). Same-box A/B, round 4 (tools/ab.py, batch 64): the pass that follows the Gabor stage
+// 0.181 -> 0.155 ms, the others 0.159 -> 0.154 ms, step 2.06 -> 2.00 ms; per-image codebooks +2 %; the deep-bank pass
+// unchanged (profiles/r4_notes.md). GCS_KP_NT=0 builds the plain-load variant for A/B runs.
+#ifndef GCS_KP_NT
+#define GCS_KP_NT 1
+#endif
+#if GCS_KP_NT
+#define GCS_KP_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define GCS_KP_LOAD(p) (*(p))
+#endif
+
 constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
                                           // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
 constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 46 KB LDS, 3 workgroups / CU
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = src[ssrc[i]];
+        for (int i = 0; i < NST; ++i) st[i] = GCS_KP_LOAD(&src[ssrc[i]]);
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
@@ -796,7 +809,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = src[min(tid + 256 * i, nchunk - 1)];
+        for (int i = 0; i < NST; ++i) st[i] = GCS_KP_LOAD(&src[min(tid + 256 * i, nchunk - 1)]);
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {

@@ -33,54 +33,81 @@ __global__ void boundary_maps_kernel(const int32_t *__restrict__ labels, const u
     }
 }
 
-__device__ __forceinline__ bool dilated5(const uint8_t *b, int H, int W, int y, int x) {
-    for (int dy = -2; dy <= 2; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -2; dx <= 2; ++dx) {
-            const int xx = x + dx;
-            if (xx >= 0 && xx < W && b[(size_t)yy * W + xx]) return true;
-        }
-    }
-    return false;
-}
-
 // counts: [b] = sum bd(L_b) for b < B; then per annotator t: [B + 3t] = sum dil5(bd(L_b)) & bd(T_t)   (recall numerator),
 // [B + 3t + 1] = sum bd(T_t) (recall denominator), [B + 3t + 2] = sum bd(L_b) & dil5(bd(T_t)) (precision numerator),
 // b = img_of[t]. With B = 1 this is the single-image layout [1 + 3A].
-__global__ void boundary_counts_kernel(const uint8_t *__restrict__ maps, const int32_t *__restrict__ img_of, int B, int T,
-                                       int H, int W, unsigned long long *__restrict__ counts) {
-    const int n = H * W;
-    const int q = blockIdx.y;                         // < B: label-only count of image q; else annotator q - B
+// One workgroup per (16 x 64 pixel tile, plane q): both boundary planes of the tile go to LDS with their two-pixel halo
+// (pixels outside the image count as "no boundary", as dilation(., rectangle(5,5)) treats its border), the 5 x 5 dilation
+// is evaluated separably (5 horizontal ORs into LDS, 5 vertical ORs per pixel) and the three sums leave the workgroup as
+// one atomic each. Round 3 walked the 25 taps in global memory with a division per pixel: 336 us for 16 BSD images and
+// their 87 annotator maps, 77 % of a segment + score loop (profiles/r4_notes.md).
+constexpr int BC_TH = 16, BC_TW = 64, BC_HALO = 2;
+__global__ __launch_bounds__(256) void boundary_counts_kernel(const uint8_t *__restrict__ maps, const int32_t *__restrict__ img_of,
+                                                              int B, int T, int H, int W, unsigned long long *__restrict__ counts) {
+    __shared__ uint8_t s_raw[2][BC_TH + 2 * BC_HALO][BC_TW + 2 * BC_HALO + 4];   // [label | annotator] boundary bits with halo
+    __shared__ uint8_t s_hor[2][BC_TH + 2 * BC_HALO][BC_TW];                     // OR over the 5 horizontal neighbours
+    __shared__ unsigned s_sum[3];
+    const size_t n = (size_t)H * W;
+    const int q = blockIdx.z;                         // < B: label-only count of image q; else annotator q - B
     const int b = q < B ? q : (img_of ? img_of[q - B] : 0);
     const uint8_t *lb = maps + (size_t)b * n;
     const uint8_t *tb = maps + (size_t)q * n;         // annotator plane (q >= B)
+    const int x0 = blockIdx.x * BC_TW, y0 = blockIdx.y * BC_TH, tid = threadIdx.x;
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        const int y = p / W, x = p % W;
-        const bool bl = lb[p];
-        if (q < B) {
-            c0 += bl;
-        } else {
-            const bool bt = tb[p];
-            c0 += bt && dilated5(lb, H, W, y, x);    // recall numerator
-            c1 += bt;                                  // recall denominator
-            c2 += bl && dilated5(tb, H, W, y, x);    // precision numerator
+    if (tid < 3) s_sum[tid] = 0;
+    if (q < B) {                                      // sum bd(L_q): no stencil
+        for (int i = tid; i < BC_TH * BC_TW; i += 256) {
+            const int y = y0 + i / BC_TW, x = x0 + i % BC_TW;
+            if (y < H && x < W) c0 += lb[(size_t)y * W + x];
+        }
+    } else {
+        constexpr int RW = BC_TW + 2 * BC_HALO, RH = BC_TH + 2 * BC_HALO;
+        for (int i = tid; i < RH * RW; i += 256) {
+            const int r = i / RW, c = i % RW, y = y0 + r - BC_HALO, x = x0 + c - BC_HALO;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            s_raw[0][r][c] = in ? lb[(size_t)y * W + x] : (uint8_t)0;
+            s_raw[1][r][c] = in ? tb[(size_t)y * W + x] : (uint8_t)0;
+        }
+        __syncthreads();
+        for (int i = tid; i < RH * BC_TW; i += 256) {
+            const int r = i / BC_TW, c = i % BC_TW;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                s_hor[m][r][c] = s_raw[m][r][c] | s_raw[m][r][c + 1] | s_raw[m][r][c + 2] | s_raw[m][r][c + 3] | s_raw[m][r][c + 4];
+        }
+        __syncthreads();
+        for (int i = tid; i < BC_TH * BC_TW; i += 256) {
+            const int r = i / BC_TW, c = i % BC_TW;
+            if (y0 + r < H && x0 + c < W) {
+                const unsigned bl = s_raw[0][r + BC_HALO][c + BC_HALO], bt = s_raw[1][r + BC_HALO][c + BC_HALO];
+                const unsigned dl = s_hor[0][r][c] | s_hor[0][r + 1][c] | s_hor[0][r + 2][c] | s_hor[0][r + 3][c] | s_hor[0][r + 4][c];
+                const unsigned dt = s_hor[1][r][c] | s_hor[1][r + 1][c] | s_hor[1][r + 2][c] | s_hor[1][r + 3][c] | s_hor[1][r + 4][c];
+                c0 += bt & dl;                        // recall numerator
+                c1 += bt;                             // recall denominator
+                c2 += bl & dt;                        // precision numerator
+            }
         }
     }
-    // wave reduction, one atomic per wave (integers: order-independent)
+    // wave reduction, then one atomic per sum and workgroup (integers: order-independent)
     for (int m = 32; m >= 1; m >>= 1) {
         c0 += __shfl_xor(c0, m);
         c1 += __shfl_xor(c1, m);
         c2 += __shfl_xor(c2, m);
     }
-    if ((threadIdx.x & 63) == 0) {
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_sum[0], c0);
+        atomicAdd(&s_sum[1], c1);
+        atomicAdd(&s_sum[2], c2);
+    }
+    __syncthreads();
+    if (tid == 0) {
         if (q < B) {
-            atomicAdd(&counts[q], (unsigned long long)c0);
+            if (s_sum[0]) atomicAdd(&counts[q], (unsigned long long)s_sum[0]);
         } else {
-            atomicAdd(&counts[B + 3 * (q - B)], (unsigned long long)c0);
-            atomicAdd(&counts[B + 3 * (q - B) + 1], (unsigned long long)c1);
-            atomicAdd(&counts[B + 3 * (q - B) + 2], (unsigned long long)c2);
+            if (s_sum[0]) atomicAdd(&counts[B + 3 * (q - B)], (unsigned long long)s_sum[0]);
+            if (s_sum[1]) atomicAdd(&counts[B + 3 * (q - B) + 1], (unsigned long long)s_sum[1]);
+            if (s_sum[2]) atomicAdd(&counts[B + 3 * (q - B) + 2], (unsigned long long)s_sum[2]);
         }
     }
 }
@@ -104,7 +131,7 @@ static int boundary_counts_launch(const int32_t *labels, const uint16_t *truth, 
     hipLaunchKernelGGL(boundary_maps_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
                        dim3(256), 0, stream, labels, truth, B, T, H, W, maps);
     GCS_CHECK_LAUNCH(who);
-    hipLaunchKernelGGL(boundary_counts_kernel, dim3(min(B + T > 64 ? 32 : 256, (n + 255) / 256), B + T), dim3(256), 0, stream,
+    hipLaunchKernelGGL(boundary_counts_kernel, dim3((W + BC_TW - 1) / BC_TW, (H + BC_TH - 1) / BC_TH, B + T), dim3(256), 0, stream,
                        maps, img_of, B, T, H, W, reinterpret_cast<unsigned long long *>(counts));
     GCS_CHECK_LAUNCH(who);
     return GCS_OK;

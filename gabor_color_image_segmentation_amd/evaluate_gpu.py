@@ -89,17 +89,19 @@ def region_counts_device(labels, truths, n_segments, n_truth_labels):
 
 
 def region_scores_from_counts(hist, area, perim, n_truth, nx, ny) -> dict:
-    """metrics.py:128-146 and :188-201 arithmetic on the integer tables, in the reference's order.
-    ``n_truth[a]`` = max(truth_a) + 1 (metrics.py:116): only those columns of annotator a exist there."""
-    n_seg = len(area)
+    """metrics.py:128-146 and :188-201 arithmetic on the integer tables, giving the reference's floats.
+    ``n_truth[a]`` = max(truth_a) + 1 (metrics.py:116): only those columns of annotator a exist there.
+
+    Where the reference adds up integer-valued terms (all far below 2^53: every order gives the same float64) the loops over
+    segments are array operations here; where it adds up fractions (per annotator, per segment of the compactness) the order of
+    the reference's loops is kept, term by term. (The per-segment Python loops of round 3 cost 0.24 ms per image - more than
+    the kernels that produce the tables.)"""
     area_f = area.astype(np.float64)
     under = 0.
     under_np = 0.
     for a in range(hist.shape[0]):
         h = hist[a][:, :int(n_truth[a])].astype(np.float64)
-        u = 0.
-        for k in range(n_seg):                                   # metrics.py:129-130 (integer-valued, exact)
-            u += area_f[k] - np.max(h[k, :])
+        u = float(np.sum(area_f - h.max(axis=1)))                # metrics.py:129-130: integer-valued terms, exact in any order
         u /= nx * ny
         under += u
         unp = float(np.sum(np.minimum(h, h.sum(axis=1)[:, None] - h)))   # metrics.py:137-139: integers, any order
@@ -107,14 +109,17 @@ def region_scores_from_counts(hist, area, perim, n_truth, nx, ny) -> dict:
         under_np += unp
     under /= hist.shape[0]
     under_np /= hist.shape[0]
-    compactness = 0
+    # metrics.py:194-201: compactness += 4 pi (a / max_area) a / perimeter^2 over the segments with a perimeter, in index order.
+    # Element by element the same float64 operations in the same order as the reference's scalar expression (perimeter^2 is
+    # an integer below 2^53: exact however it is computed); the sum itself stays a left-to-right loop.
     max_area = float(nx * ny)
-    for i in range(n_seg):                                       # metrics.py:194-201, same operation order
-        a_i = np.int64(area[i])
-        perimeter = np.float64(perim[i])
-        ratio = a_i / max_area
-        if perimeter > 0:
-            compactness += 4 * pi * ratio * a_i / pow(perimeter, 2)
+    a64 = area.astype(np.int64)
+    per = perim.astype(np.float64)
+    has = per > 0
+    terms = 4 * pi * (a64[has] / max_area) * a64[has] / (per[has] * per[has])
+    compactness = 0
+    for t in terms:
+        compactness += t
     return {"underseg": float(under), "undersegNP": float(under_np), "compactness": float(compactness)}
 
 

@@ -20,7 +20,13 @@ import numpy as np
 from . import _lib
 from .bank import GaborBank, make_bank
 
-_SLAB_BUDGET = 16 << 30    # feature-slab bytes per group; measured: one big launch beats cache-sized groups
+# Feature-slab bytes per group of a per-image batch. Large on purpose: measured in round 4 with the current kernels
+# (tools/cache_resident_pass.py, profiles/r4_notes.md "Infinity-Cache-resident groups"): a pass that re-reads a slab small enough
+# to stay in the 256 MiB Infinity Cache (8 images, 112 MB) streams it at 3.8 TB/s, 16 images (224 MB) at 4.9 TB/s, the
+# 64-image slab (895 MB, from HBM) at 5.9 TB/s - a pass costs ~12 us of launch, prologue and fold however few bytes it reads,
+# and what remains is the same 6.4-6.6 TB/s per byte in all three cases (the staging structure, not HBM, sets the rate). 64
+# images in cache-sized groups of 16 take 2.45 ms against 2.04 ms in one group.
+_SLAB_BUDGET = 16 << 30
 # host calls up to this many pixels replay a captured HIP graph of the whole step
 _GRAPH_MAX_PIXELS = 1 << 20
 

@@ -16,4 +16,9 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU 
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc/$tag -- python $R/tools/stage_time.py 64 8 8 > $OUT/pmc_$tag.log 2>&1
 done
 python $R/tools/pmc_summary.py $OUT/pmc > $R/gpurun_out/profiles/${TAG}_config4_pmc.txt
+# HBM traffic: separate passes, never combined with other counters (FETCH_SIZE doubled on gfx950: tools/hbm_traffic.py)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/hbm/$c -- python $R/tools/stage_time.py 64 8 8 > $OUT/hbm_$c.log 2>&1
+done
+python $R/tools/hbm_traffic.py $OUT/hbm $R/gpurun_out/profiles/${TAG}_config4_hbm_traffic.json
 cat $R/gpurun_out/profiles/${TAG}_config4_stage_time.txt $R/gpurun_out/profiles/${TAG}_config4_pmc.txt

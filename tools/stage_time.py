@@ -36,7 +36,7 @@ def timed(fn, n=10, warm=2):
 
 tg = timed(lambda: seg.ops.gabor_features(imgs, ws["feats"]))
 seg.ops.kmeans_init(ws["feats"], B, H, W, k, n_sets, ws["cent"])
-tp = timed(lambda: seg.ops.assign_accumulate(ws["feats"], ws["cent"], B, H, W, k, n_sets, ws["labels"], ws["partials"]))
+tp = timed(lambda: seg.ops.assign_accumulate(ws["feats"], ws["cent"], B, H, W, k, n_sets, None, ws["partials"]))   # sums only, as in a step
 ts = timed(lambda: seg.segment_device(imgs, mode=mode), n=5, warm=1)
 px = B * H * W
 bank = seg.bank
