@@ -230,18 +230,17 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
-// The slab is read once per pass and is far larger than every cache: the tile loads carry the nontemporal hint
-// (global_load_dwordx4 ... nt). Same-box A/B, round 4 (tools/ab.py, batch 64): the pass that follows the Gabor stage
-// 0.181 -> 0.155 ms, the others 0.159 -> 0.154 ms, step 2.06 -> 2.00 ms; per-image codebooks +2 %; the deep-bank pass
-// unchanged (profiles/r4_notes.md). GCS_KP_NT=0 builds the plain-load variant for A/B runs.
-#ifndef GCS_KP_NT
-#define GCS_KP_NT 1
-#endif
-#if GCS_KP_NT
-#define GCS_KP_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define GCS_KP_LOAD(p) (*(p))
-#endif
+// Tile loads of the passes. A slab far larger than the 256 MiB Infinity Cache is read once per pass and nothing of it survives
+// to the next one: its loads carry the nontemporal hint (global_load_dwordx4 ... nt) and stop evicting what other kernels
+// keep there. Same-box A/B, round 4, batch 64 (895 MB): in a sequence that interleaves other work (tools/ab.py) the pass after
+// the Gabor stage 0.181 -> 0.155 ms, the others 0.159 -> 0.154 ms, step 2.06 -> 2.00 ms; in bench.py's back-to-back steps no
+// difference (4 820 / 4 777 vs 4 822 / 4 769 Mpix/s). Slabs the cache can hold a good part of lose with the hint (16 images,
+// 224 MB: 4 007 -> 3 910 Mpix/s; 8 images: 2 996 -> 2 886): the host sets `nt` from the slab size (profiles/r4_notes.md).
+constexpr size_t KP_NT_MIN_SLAB_BYTES = (size_t)512 << 20;
+template <typename T>
+__device__ __forceinline__ T kp_load(const T *p, bool nt) {
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
 
 constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
                                           // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
@@ -263,8 +262,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials, void *__restrict__ raster,
-    int raster_u8) {
+    int raster_u8, int nt_flag) {
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
+    const bool nt_loads = __builtin_amdgcn_readfirstlane(nt_flag) != 0;     // (uniform: a scalar branch around the two load forms)
     constexpr int NTHR = 64 * WAVES;                         // threads per workgroup
     constexpr int NT_OWN = WAVES == 8 ? (KP_NT + 1) / 2 : KP_NT;   // update plane tiles a wave accumulates
     // compact copy of pyramid levels >= 2 of one tile (level 1 is replicated straight from the staging registers):
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = GCS_KP_LOAD(&src[ssrc[i]]);
+        for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[ssrc[i]], nt_loads);
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
@@ -700,7 +700,8 @@ template <int NL, int NT, int NST, int MINB>
 __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials,
-    void *__restrict__ raster, int raster_u8) {
+    void *__restrict__ raster, int raster_u8, int nt_flag) {
+    const bool nt_loads = __builtin_amdgcn_readfirstlane(nt_flag) != 0;
     constexpr int TILE_B = (NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END) + 512;   // + room for the over-reads of unused columns
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[TILE_B];
     __shared__ __attribute__((aligned(16))) int2 s_part[4][NL - 1][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = GCS_KP_LOAD(&src[min(tid + 256 * i, nchunk - 1)]);
+        for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[min(tid + 256 * i, nchunk - 1)], nt_loads);
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
@@ -1158,10 +1159,11 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         // (assign_accumulate with labels: every pixel of the image is labelled, halo rows of a row window included)
         void *lab_out = raster ? raster : static_cast<void *>(labels);
         const int lab_u8 = raster ? raster_u8 : 1;
+        const int nt_flag = (size_t)B * lo.ntiles * lo.tile_bytes >= KP_NT_MIN_SLAB_BYTES ? 1 : 0;   // see kp_load
 #define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
-                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
 #define GCS_KP_LAUNCH(KT_, NST_, DS_) GCS_KP_LAUNCHW(KT_, NST_, DS_, 4)
         const int nchunk = lo.tile_bytes / 16;
         const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
@@ -1187,7 +1189,7 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
     hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
-                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
                 if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
                 else if (lo.n_levels == 3) GCS_NV_LAUNCH(3);
                 else GCS_NV_LAUNCH(4);
