@@ -100,73 +100,93 @@ extern "C" int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_
     return GCS_OK;
 }
 
-// Level-0 pre-pass. A thread produces 4 consecutive bytes of GP_ROWS consecutive padded plane rows for the three channels:
-//   plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128 (interleaved uint8 RGB -> planar int8 with the reflect
-//   border and the tile over-read materialised, so the main kernel stages tiles as aligned 16-byte copies with no index
-//   arithmetic).
-// Away from the borders the 4 pixels are 12 contiguous source bytes: they are fetched with unaligned dword loads (gfx950
-// global memory takes any byte alignment) and de-interleaved with v_perm_b32 (3 per channel dword).
+// Level-0 pre-pass: plane[b][c][r][u] = img[b][refl(r-7)][refl(u-7)][c] - 128 (interleaved uint8 RGB -> planar int8 with
+// the reflect border and the tile over-read materialised, so the MFMA kernel stages tiles as aligned 16-byte copies with no
+// index arithmetic). A work item = 16 consecutive bytes of one plane row for the three channels. Away from the left / right
+// borders the 16 pixels are 48 contiguous source bytes: three 16-byte loads at any byte alignment (gfx950 global memory
+// takes them), de-interleaved with v_perm_b32 (9 per 4 pixels), three aligned 16-byte stores. Items that touch a border or
+// the padding go pixel by pixel through reflect(); they are walked in a loop of their own, so that no wave mixes the two
+// paths. Round 3's form (4 bytes x 4 rows per thread) took 36-45 us per 64 images in front of the level-0 MFMA launch -
+// on the stage's critical path (profiles/r4_notes.md); two items per thread are in flight here.
 typedef unsigned __attribute__((aligned(1))) unaligned_u32;
+typedef int __attribute__((ext_vector_type(4), aligned(1))) v4i_a1;
 typedef short v2s __attribute__((ext_vector_type(2)));
 
-constexpr int GP_ROWS = 4;   // plane rows per thread: their loads are issued together (the kernel is latency-bound)
+__device__ __forceinline__ void plane_deinterleave4(unsigned d0, unsigned d1, unsigned d2, unsigned &r, unsigned &g, unsigned &b) {
+    // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> one dword per channel, then pixel - 128
+    const unsigned r01 = __builtin_amdgcn_perm(d1, d0, 0x07060300u);   // R0 R1 . .   (bytes 0, 3 of d0; 6, 7 unused)
+    const unsigned g01 = __builtin_amdgcn_perm(d1, d0, 0x07060401u);   // G0 G1 . .   (byte 1 of d0, byte 0 of d1)
+    const unsigned b01 = __builtin_amdgcn_perm(d1, d0, 0x07060502u);   // B0 B1 . .   (byte 2 of d0, byte 1 of d1)
+    const unsigned r23 = __builtin_amdgcn_perm(d2, d1, 0x05020000u);   // . . R2 R3   (byte 2 of d1, byte 1 of d2)
+    const unsigned g23 = __builtin_amdgcn_perm(d2, d1, 0x06030000u);   // . . G2 G3   (byte 3 of d1, byte 2 of d2)
+    const unsigned b23 = __builtin_amdgcn_perm(d2, d2, 0x03000000u);   // . . B2 B3   (bytes 0, 3 of d2)
+    r = __builtin_amdgcn_perm(r23, r01, 0x07060100u) ^ 0x80808080u;
+    g = __builtin_amdgcn_perm(g23, g01, 0x07060100u) ^ 0x80808080u;
+    b = __builtin_amdgcn_perm(b23, b01, 0x07060100u) ^ 0x80808080u;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
                                                           int Hp, int Wp, int8_t *__restrict__ planes,
                                                           uint8_t *__restrict__ img_out) {
     static_assert(MODE == 0, "levels >= 1 use gabor_down_kernel");
-    const int b = blockIdx.z;
-    const int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * GP_ROWS;   // GP_ROWS consecutive plane rows per thread
-    if (r0 >= Hp) return;
-    for (int u4 = blockIdx.x * 64 + (threadIdx.x & 63); u4 < Wp / 4; u4 += gridDim.x * 64) {
-        const int l0 = 4 * u4 - G_HALO;                              // level column of this thread's first byte
-        const bool interior = l0 >= 0 && l0 + 3 < WL;
-        unsigned o[GP_ROWS][3];
-        if (interior) {
-            // 4 pixels = 12 contiguous source bytes per row, fetched with unaligned dword loads
-            unsigned d[GP_ROWS][3];
+    const int b = blockIdx.y;
+    const int ng = Wp / 16;                                          // 16-byte groups per plane row
+    // interior groups g: level columns 16 g - 7 .. 16 g + 8 all inside [0, WL)
+    const int g_lo = 1, g_hi = WL >= 25 ? (WL - 9) / 16 : 0;         // interior: g_lo <= g <= g_hi (none for narrow levels)
+    const int n_in = g_hi >= g_lo ? g_hi - g_lo + 1 : 0;
+    const int n_bd = ng - n_in;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    int8_t *pb = planes + (size_t)b * 3 * Hp * Wp;
+    const size_t cstride = (size_t)Hp * Wp;
+    // ---- interior items, two per thread in flight
+    const int items_in = Hp * n_in;
+    for (int it = tid; it < items_in; it += 2 * nthr) {
+        const int it1 = it + nthr < items_in ? it + nthr : it;       // (the last round repeats an item: same bytes twice)
+        v4i s[2][3];
+        int rr[2], gg[2];
 #pragma unroll
-            for (int j = 0; j < GP_ROWS; ++j) {
-                const int ly = reflect(min(r0 + j, Hp - 1) - G_HALO, HL);
-                const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + l0) * 3;
+        for (int j = 0; j < 2; ++j) {
+            const int i = j ? it1 : it;
+            rr[j] = i / n_in;
+            gg[j] = g_lo + (i - rr[j] * n_in);
+            const int ly = reflect(rr[j] - G_HALO, HL);
+            const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + (16 * gg[j] - G_HALO)) * 3;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) d[j][i] = *reinterpret_cast<const unaligned_u32 *>(p + 4 * i);
-            }
-#pragma unroll
-            for (int j = 0; j < GP_ROWS; ++j) {
-                // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> one dword per channel, then pixel - 128
-                const unsigned d0 = d[j][0], d1 = d[j][1], d2 = d[j][2];
-                const unsigned r01 = __builtin_amdgcn_perm(d1, d0, 0x07060300u);   // R0 R1 . .   (bytes 0, 3 of d0; 6, 7 unused)
-                const unsigned g01 = __builtin_amdgcn_perm(d1, d0, 0x07060401u);   // G0 G1 . .   (byte 1 of d0, byte 0 of d1)
-                const unsigned b01 = __builtin_amdgcn_perm(d1, d0, 0x07060502u);   // B0 B1 . .   (byte 2 of d0, byte 1 of d1)
-                o[j][0] = __builtin_amdgcn_perm(d2, d1, 0x05020000u);              // . . R2 R3   (byte 2 of d1, byte 1 of d2)
-                o[j][1] = __builtin_amdgcn_perm(d2, d1, 0x06030000u);              // . . G2 G3   (byte 3 of d1, byte 2 of d2)
-                o[j][2] = __builtin_amdgcn_perm(d2, d2, 0x03000000u);              // . . B2 B3   (bytes 0, 3 of d2)
-                o[j][0] = (__builtin_amdgcn_perm(o[j][0], r01, 0x07060100u)) ^ 0x80808080u;
-                o[j][1] = (__builtin_amdgcn_perm(o[j][1], g01, 0x07060100u)) ^ 0x80808080u;
-                o[j][2] = (__builtin_amdgcn_perm(o[j][2], b01, 0x07060100u)) ^ 0x80808080u;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < GP_ROWS; ++j) {
-                const int ly = reflect(min(r0 + j, Hp - 1) - G_HALO, HL);
-                o[j][0] = o[j][1] = o[j][2] = 0u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int lx = reflect(4 * u4 + e - G_HALO, WL);
-                    const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + lx) * 3;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) o[j][c] |= ((unsigned)p[c] ^ 0x80u) << (8 * e);
-                }
-            }
+            for (int q = 0; q < 3; ++q) s[j][q] = *reinterpret_cast<const v4i_a1 *>(p + 16 * q);
         }
 #pragma unroll
-        for (int j = 0; j < GP_ROWS; ++j)
-            if (r0 + j < Hp)
+        for (int j = 0; j < 2; ++j) {
+            const unsigned d[12] = {(unsigned)s[j][0][0], (unsigned)s[j][0][1], (unsigned)s[j][0][2], (unsigned)s[j][0][3],
+                                    (unsigned)s[j][1][0], (unsigned)s[j][1][1], (unsigned)s[j][1][2], (unsigned)s[j][1][3],
+                                    (unsigned)s[j][2][0], (unsigned)s[j][2][1], (unsigned)s[j][2][2], (unsigned)s[j][2][3]};
+            unsigned o[3][4];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r0 + j) * Wp + 4 * u4) = o[j][c];
+            for (int q = 0; q < 4; ++q) plane_deinterleave4(d[3 * q], d[3 * q + 1], d[3 * q + 2], o[0][q], o[1][q], o[2][q]);
+            int8_t *dst = pb + (size_t)rr[j] * Wp + 16 * gg[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<v4i *>(dst + c * cstride) = v4i{(int)o[c][0], (int)o[c][1], (int)o[c][2], (int)o[c][3]};
+        }
+    }
+    // ---- border / padding items: pixel by pixel through reflect()
+    const int items_bd = Hp * n_bd;
+    for (int it = tid; it < items_bd; it += nthr) {
+        const int r = it / n_bd, k = it - r * n_bd;
+        const int g = k < g_lo ? k : k + n_in;                       // groups 0 .. g_lo-1, then g_hi+1 .. ng-1
+        const int ly = reflect(r - G_HALO, HL);
+        unsigned o[3][4] = {};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lx = reflect(16 * g + e - G_HALO, WL);
+            const uint8_t *p = src + (((size_t)b * Hs + ly) * Ws + lx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c][e >> 2] |= ((unsigned)p[c] ^ 0x80u) << (8 * (e & 3));
+        }
+        int8_t *dst = pb + (size_t)r * Wp + 16 * g;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<v4i *>(dst + c * cstride) = v4i{(int)o[c][0], (int)o[c][1], (int)o[c][2], (int)o[c][3]};
     }
 }
 
@@ -638,8 +658,6 @@ struct StripArgs {
     StripLevel lv[2];
     int n_levels, tasks_per_image;
 };
-typedef int __attribute__((ext_vector_type(4), aligned(1))) v4i_a1;
-
 template <int KS>
 __global__ __launch_bounds__(256) void gabor_strip_kernel(StripArgs A, GcsLayout lo, int shift, unsigned char *__restrict__ feats,
                                                           int total_tasks) {
@@ -850,7 +868,9 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     for (int L = 0; L < lo.n_levels; ++L) {
         int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
         const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
-        const dim3 pgrid((Wp / 4 + 63) / 64, (Hp + 4 * GP_ROWS - 1) / (4 * GP_ROWS), B);
+        // level-0 pre-pass: about two interior items (16 bytes x 3 channels) per thread and loop round
+        const int pitems = Hp * (Wp / 16);
+        const dim3 pgrid((pitems + 511) / 512, B);
         uint8_t *img_out = (L >= 1 && L + 1 < lo.n_levels) ? wsb + ws.img_off[L] : nullptr;
         if (L == 0)
             hipLaunchKernelGGL((gabor_plane_kernel<0>), pgrid, block, 0, GCS_STREAM_OF(L), img, H, W, HL, WL, Hp, Wp, planes,
