@@ -120,21 +120,24 @@ def cpu_baseline(batch, k, n_iter, mode):
 
 
 class TimedOps:
-    """Wraps HipOps: HIP events (on the launch stream) around the two streaming kernels.
+    """Wraps HipOps: HIP events (on the launch stream) around the two streaming kernels, SAMPLED.
 
-    Every Gabor launch is bracketed; of the Lloyd passes every PASS_STRIDE-th launch is (stride 11 against 10
-    passes per step: the sampled position walks through all ten passes, forward and reverse sweeps alike, the LAST
-    pass included - it goes through assign_raster, stores the raster label map and accumulates nothing, and its
-    bytes are part of `a_bytes`, so it has to be part of the average too).
-    Each event costs ~5.7 us of stream time (rocprofv3 kernel trace: that is the gap before a kernel that
-    follows a record, 0.0 us otherwise); bracketing all 11 launches of a step made the step 2 % slower."""
-    PASS_STRIDE = 11
+    Each event costs ~5.7 us of stream time (rocprofv3 kernel trace: that is the gap before a kernel that follows a
+    record, 0.0 us otherwise). Bracketing every Gabor call and every 11th pass made the timed region 1 % slower than
+    `--no-events` (round 4, same box: 4 764 vs 4 817 Mpix/s), so the sampling is sparser now: every GABOR_STRIDE-th Gabor
+    call and every PASS_STRIDE-th Lloyd pass (23 against 10 passes per step: the sampled position walks through all ten
+    passes, forward and reverse sweeps alike, the LAST pass included - it goes through assign_raster, stores the raster
+    label map and accumulates nothing, and its bytes are part of `a_bytes`, so it has to be part of the average too).
+    20 timed steps give 5 Gabor samples and 8-9 pass samples."""
+    PASS_STRIDE = 23
+    GABOR_STRIDE = 4
 
     def __init__(self, ops, torch):
         self._ops, self._torch = ops, torch
         self.events = {"gabor": [], "assign": []}
         self.enabled = False
         self._n_pass = 0
+        self._n_gabor = 0
 
     def __getattr__(self, name):
         return getattr(self._ops, name)
@@ -150,6 +153,9 @@ class TimedOps:
         self.events[key].append((s, e))
 
     def gabor_features(self, *a, **kw):
+        self._n_gabor += 1
+        if self._n_gabor % self.GABOR_STRIDE != 1:
+            return self._ops.gabor_features(*a, **kw)
         return self._timed("gabor", self._ops.gabor_features, *a, **kw)
 
     def _pass(self, fn, *a, **kw):
@@ -258,7 +264,7 @@ def main():
             step(mode)
         barrier()
         tops.enabled = events
-        tops._n_pass = 0
+        tops._n_pass = tops._n_gabor = 0
         t0 = time.perf_counter()
         for _ in range(steps):
             step(mode)

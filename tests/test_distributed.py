@@ -76,12 +76,15 @@ def test_row_sharded_image_equals_unsharded_oracle(tmp_path, world):
 
 
 @pytest.mark.gpu
-def test_row_sharded_image_on_gpu_two_ranks(tmp_path, built):
-    """Same, through the HIP kernels: two processes share cuda:0, gloo carries the tiny collectives."""
+@pytest.mark.parametrize("height,width", [(200, 136), (202, 137)])
+def test_row_sharded_image_on_gpu_two_ranks(tmp_path, built, height, width):
+    """Same, through the HIP kernels: two processes share cuda:0, gloo carries the tiny collectives. 202 x 137: the second
+    rank's strip is 114 rows of 137 pixels - a two-row bottom edge and a one-pixel right edge, i.e. the packed edge strips of
+    the slab (csrc/common.h) together with a row window (halo rows labelled, not voting)."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import c_oracle as co, spec_oracle as so
-    port = 33500 + (os.getpid() % 2000)
-    b, height, width = 1, 200, 136
+    port = 33500 + (os.getpid() % 2000) + height
+    b = 1
     mp.spawn(_strip_worker, args=(2, port, b, height, width, 5, 8, str(tmp_path), True), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(2)], axis=1)
     tapq, shift = so.bank()

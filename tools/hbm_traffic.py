@@ -14,6 +14,7 @@ for f in glob.glob(out_dir + "/*/*/*counter_collection.csv"):
         n = r["Kernel_Name"]
         key = "gabor_mfma_kernel" if "gabor_mfma_kernel" in n else "kmeans_pass_mfma_kernel" if "kmeans_pass_mfma" in n else \
               "kmeans_pass_native_kernel" if "kmeans_pass_native" in n else \
+              "gabor_strip_kernel" if "gabor_strip" in n else \
               "gabor_plane_kernel" if ("gabor_plane" in n or "gabor_down" in n) else None
         if key:
             acc[(key, n.split("(")[0].replace("void ", "").strip(), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
