@@ -468,8 +468,8 @@ def main():
             import scoring_rate
             log("scoring throughput (24 BSD val images)")
             extra["scoring"] = scoring_rate.measure(seg, reps=3)
-        except FileNotFoundError as e:             # the golden pack is part of the repo; a stripped copy simply skips this
-            extra["scoring"] = {"skipped": str(e)}
+        except Exception as e:                     # an extra, never a reason to lose the bench line (e.g. a copy without tests/golden)
+            extra["scoring"] = {"skipped": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
