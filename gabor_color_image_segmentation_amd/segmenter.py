@@ -724,12 +724,26 @@ class Segmenter:
                 step()                                     # eager once: first-use work (side-stream creation) outside the capture
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
+                # A torch CUDAGraph that is DESTROYED while a capture is open throws out of its destructor ("operation not
+                # permitted when stream is capturing") and std::terminate ends the process - and this torch no longer
+                # collects garbage before a capture (torch.compiler.config.force_cudagraph_gc is off). Dead reference cycles
+                # that hold a graph (the caller's, another library's; round 4: dead plans of this module, see
+                # profiles/r4_notes.md) must not be finalised between capture_begin and capture_end: collect them now and
+                # keep the cyclic collector off meanwhile. thread_local: only this thread is restricted while it captures
+                # (the default mode fails the allocations and frees of every other thread, and lets theirs fail this capture).
+                import gc
+                gc.collect()
+                gc_was_enabled = gc.isenabled()
+                gc.disable()
                 try:
-                    with torch.cuda.graph(graph):
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         step()
                 except RuntimeError:                       # capture refused (e.g. another capture is open): launch eagerly
                     graph = None
                     torch.cuda.synchronize(dev)
+                finally:
+                    if gc_was_enabled:
+                        gc.enable()
                 ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in, scratch=scratch)
                 if len(self._graphs) >= 4:
                     self._graphs.pop(next(iter(self._graphs)))

@@ -20,8 +20,8 @@ for case in range(n_cases):
     ks = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 13, 13, 15]))
     if ns * no * 3 > 207 and rng.random() < 0.7:
         no = max(1, 69 // ns)
-    h = int(rng.choice([8, 9, 17, 31, 32, 33, 36, 63, 64, 65, 97, 129, 161, 200, 321]))
-    w = int(rng.choice([8, 11, 24, 40, 63, 64, 65, 72, 96, 130, 200, 257, 481]))
+    h = int(rng.choice([8, 9, 10, 17, 31, 32, 33, 34, 36, 63, 64, 65, 66, 97, 129, 161, 200, 321]))
+    w = int(rng.choice([8, 10, 11, 24, 40, 42, 63, 64, 65, 72, 96, 130, 200, 257, 481, 482]))
     b = int(rng.choice([1, 1, 2, 3, 5, 9]))
     k = int(rng.choice([1, 2, 5, 8, 8, 11, 16]))
     n_iter = int(rng.choice([1, 2, 3]))

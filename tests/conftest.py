@@ -17,7 +17,20 @@ def pytest_configure(config):
         import gc
         import torch  # noqa: F401  (load the HIP runtime first: whoever installs handlers at load time goes before us)
         ctypes.CDLL(os.path.join(ROOT, "tools", "dbg", "abrt_bt.so")).abrt_bt_install()
-        gc.set_debug(gc.DEBUG_COLLECTABLE)
+        if "gc" in os.environ["GCS_DEBUG_ABORT"]:
+            gc.set_debug(gc.DEBUG_COLLECTABLE)
+        if "cycle" in os.environ["GCS_DEBUG_ABORT"]:
+            # re-create round 4's reference cycle (graph entry -> plan): dead plans then pile up until a cyclic collection,
+            # the condition under which the session aborted (profiles/r4_notes.md)
+            from gabor_color_image_segmentation_amd import segmenter as _sg
+            _orig = _sg.Segmenter._segment_small
+
+            def _cyclic(self, *a, **kw):
+                out = _orig(self, *a, **kw)
+                for ent in self._graphs.values():
+                    ent["_plan"] = self
+                return out
+            _sg.Segmenter._segment_small = _cyclic
 
 
 @pytest.fixture(scope="session")
