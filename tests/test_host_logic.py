@@ -113,3 +113,19 @@ def test_segment_images_bounds_what_waits_behind_a_rare_shape():
         assert np.array_equal(g, so.segment(im, n_iter=2))
     # the first result left while at most 2 * batch + batch images had been taken from the loader, not at its end
     assert yielded_at[0] <= 3 * batch + 1 < n
+
+
+def test_debug_switches_parse_and_reject_unknown_names():
+    """The one set of measurement / test switches (GCS_DEBUG=...): every name is documented in segmenter.DebugSwitches, an
+    unknown one is an error instead of a silently ignored typo, and a plan carries its own copy."""
+    from gabor_color_image_segmentation_amd.segmenter import DebugSwitches
+    d = DebugSwitches("no_reverse, slab_candidates=3,force_collectives")
+    assert d.no_reverse and d.force_collectives and not d.no_graph and d.slab_candidates == 3
+    assert not any(vars(DebugSwitches("")).values())
+    with pytest.raises(ValueError):
+        DebugSwitches("no_revrse")
+    with pytest.raises(ValueError):
+        DebugSwitches("no_graph=1")
+    a, b = _seg(), _seg()
+    a.debug.force_collectives = True
+    assert not b.debug.force_collectives
