@@ -6,6 +6,8 @@
 //   gabor_plane_kernel      level 0: interleaved RGB -> planar (pixel - 128) with the reflect border materialised.
 //   gabor_down_kernel       level L >= 1: 2x2 block mean of level L-1 (round half up, edge replication), written as the
 //                           padded plane of level L and, when a further level follows, as a compact image.
+//   gabor_strip_kernel      the packed edge strips of the slab (csrc/common.h): right / bottom edges of one or two pixels of
+//                           every level of a bank of at most two levels, outside the MFMA kernel's tile grid.
 //   gabor_mfma_kernel       one pyramid level: A = packed 2-digit int8 taps of the level's filters (rows = filter x
 //                           {re_lo,re_hi,im_lo,im_hi} x two pixel shifts, resident in registers), B = (pixel-128) windows
 //                           read as aligned 16-byte pieces of an LDS tile kept twice (second copy two bytes to the right;
