@@ -320,7 +320,7 @@ def main():
     }
     if g_ms >= a_ms * args.n_iter:    # dominant = larger share of the step (`launches` = launches bracketed by events)
         kg = kernels["gabor_mfma_kernel"]
-        # arithmetic intensity 81000 op / 93 B = 871 op/B is above the int8 ridge (5 POP/s / 8 TB/s =
+        # arithmetic intensity 60 840 op / 93 B = 654 op/B is above the int8 ridge (5 POP/s / 8 TB/s =
         # 625 op/B): the MFMA roof bounds this kernel; the HBM fraction is reported next to it.
         roofline = dict(kernel="gabor_mfma_kernel", bound="mfma", achieved=kg["tops"], peak=I8_MFMA_PEAK_TOPS,
                         unit="TFLOP/s", frac=kg["mfma_frac"], traffic=None, ops="int8 MAC x2 (TOP/s)",

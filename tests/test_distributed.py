@@ -255,7 +255,7 @@ def _owned_rows_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_
 @pytest.mark.parametrize("world", [2, 3])
 def test_halo_exchange_between_ranks_equals_unsharded_oracle(tmp_path, world):
     """BASELINE config 5 with the cross-rank halo exchange (SURVEY §8e option (ii)): every rank holds only its own rows;
-    the 14 halo rows per interior edge travel rank to rank (point-to-point), nothing comes from a host copy of the whole
+    the 12 halo rows per interior edge travel rank to rank (point-to-point), nothing comes from a host copy of the whole
     image. Result == the unsharded oracle."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so

@@ -1,8 +1,9 @@
 /* LD_PRELOAD helper (diagnostics only): a native backtrace of whoever ends the process abnormally, to stderr.
  *   - interposes abort(): std::terminate, failed assertions of C++ runtimes, explicit aborts (callers that go through the PLT);
- *   - SIGABRT / SIGSEGV / SIGBUS handlers for the rest (abrt_bt_install() re-installs them late, from tests/conftest.py).
+ *   - SIGABRT / SIGSEGV / SIGBUS handlers for the rest (abrt_bt_install(): call it late through ctypes if another library
+ *     installs handlers of its own at load time).
  * Run with LIBC_FATAL_STDERR_=1 so that glibc's own messages (heap corruption: it calls its internal abort) reach stderr too.
- * build: gcc -shared -fPIC -O1 -o tools/dbg/abrt_bt.so tools/dbg/abrt_bt.c -ldl ; run pytest with -p no:faulthandler */
+ * build: make -C tools/dbg ; run: LD_PRELOAD=tools/dbg/abrt_bt.so ABRT_BT_FILE=/tmp/bt.txt python -m pytest -p no:faulthandler ... */
 #define _GNU_SOURCE
 #include <execinfo.h>
 #include <signal.h>

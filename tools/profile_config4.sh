@@ -4,9 +4,9 @@
 # Usage on the GPU box:  bash tools/profile_config4.sh r1
 set -e
 TAG=${1:-r1}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 OUT=$R/gpurun_out/prof_c4_$TAG
-rm -rf $OUT     # (gpurun merges gpurun_out/ across calls: never mix two runs' counter files)
+rm -rf "$OUT"     # (gpurun merges gpurun_out/ across calls: never mix two runs' counter files)
 mkdir -p $OUT $R/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/tools/stage_time.py 64 8 8 > $OUT/stage.log 2>&1

@@ -4,9 +4,9 @@
 # Usage on the GPU box:  bash tools/profile_round.sh r1     -> gpurun_out/prof_r1/, summaries under profiles/
 set -e
 TAG=${1:-r1}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 OUT=$R/gpurun_out/prof_$TAG
-rm -rf $OUT     # (gpurun merges gpurun_out/ across calls: never mix two runs' counter files)
+rm -rf "$OUT"     # (gpurun merges gpurun_out/ across calls: never mix two runs' counter files)
 mkdir -p $OUT $R/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-other-mode > $OUT/bench_trace.log 2>&1
