@@ -661,29 +661,38 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 // ---------------------------------------------------------------------------------------
 // One Lloyd pass for DEEP banks (80 <= D <= 207 with at most 48 planes on every pyramid level, k <= 8: the 8x8 bank of
 // BASELINE config 4), every level consumed at its OWN resolution. The tile goes to LDS as it sits in HBM (32.6 KB for
-// the 8x8 bank) instead of being replicated to 208 full-resolution plane rows (106 KB), so two workgroups share a CU:
+// the 8x8 bank) instead of being replicated to 208 full-resolution plane rows (106 KB):
 //   assign:  per level L the partial scores S_L[(j,pat)][parent] = A_pat^L * X^L on v_mfma_i32_32x32x32_i8 (3 K-steps of
 //            16 planes per level; N = the block's 64 pixels, 16 / 4 / 1 parents). The key of SPEC.md §4 is linear in the
 //            planes: key_j(px) = base_j - 32 U - 2^21 R2 with U = R0 + 256 R1 and (U, R2) summed over the levels at the
 //            pixel's parents; the coarse (U, R2) pairs travel through a wave-private LDS table.
-//   update:  sums[j][plane of L] = cnt_L[j][parent] * X^L[parent][plane] on v_mfma_i32_16x16x64_i8, where cnt_L counts the
-//            voting pixels of label j under a parent (level 0: the one-hot digit -128 as in the other pass; coarse
-//            levels: small positive counts built from the one-hot bytes); n_j by v_bcnt.
+//   update:  (round 5) rows of the MFMA = (cluster j, byte b) - k <= 8 fills the 16 rows -, K = (pixel or parent, byte),
+//            columns = 16 PLANES: sums[(j, b)][plane] = sel[(j, b)][(px, t)] * X[(px, t)][plane] with sel = the one-hot digit
+//            (level 0: -128) or the count of voting pixels of label j under the parent (coarse levels) where t == b, 0
+//            elsewhere. The B operand is then the plane row AS IT LIES in LDS (16 bytes = 8 pixels x (lo, hi): no byte
+//            de-interleave), and a level's 48 planes are 3 accumulator tiles instead of 6: 48 accumulator VGPRs for the four
+//            levels instead of 96 - with the compact tables below what lets THREE workgroups share a CU (168 VGPRs,
+//            52.5 KB of LDS) instead of two. Level 0 on v_mfma_i32_16x16x64_i8 (two 32-pixel halves), the coarse levels on
+//            v_mfma_i32_16x16x32_i8 (8 / 4 / 2 of the 8 K-slots of a lane group); n_j by v_bcnt.
 // Same tile list, sweep order, validity rules, outputs and partial layout as kmeans_pass_mfma_kernel.
-constexpr int NV_DL = 48, NV_KS = 3;                         // planes (LDS rows) and assign K-steps per level
+constexpr int NV_DL = 48, NV_KS = 3, NV_UT = 3;              // planes (LDS rows), assign K-steps and update plane tiles per level
+constexpr int NV_NST = 8;                                     // 16-byte staging chunks per thread (tile_bytes <= 32 768)
 constexpr int NV_P0 = KP_TP * 2 + 64, NV_P1 = 128 + 32, NV_P2 = 32, NV_P3 = 8;   // LDS bytes per plane row of level L
 constexpr int NV_OFF1 = NV_DL * NV_P0, NV_OFF2 = NV_OFF1 + NV_DL * NV_P1, NV_OFF3 = NV_OFF2 + NV_DL * NV_P2;
 constexpr int NV_END = NV_OFF3 + NV_DL * NV_P3;
+constexpr int NV_PART_W = 8 * (16 + 4 + 1);                  // (U, R2) pairs per wave: [cluster][16 | 4 | 1 parents of level 1 | 2 | 3]
+constexpr int NV_APAT_SLOTS = 49;                             // A fragments per (level, K-step): 8 clusters x 3 patterns x 2 K-halves + one zero slot
 
 // B fragments by hardware transpose (see kmeans_pass_mfma_kernel): issue only; nv_wait() then waits once for everything
-template <int PITCH>
+template <int PITCH, int OFS = 0>
 __device__ __forceinline__ void nv_issue(unsigned addr, v2i (&fa)[NV_KS], v2i (&fb)[NV_KS]) {
+    static_assert(OFS + (NV_KS - 1) * 16 * PITCH + 4 * PITCH < 65536, "K-step offsets must fit the 16-bit DS offset field");
 #pragma unroll
-    for (int kk = 0; kk < NV_KS; ++kk)
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
-                     "ds_read_b64_tr_b16 %1, %2 offset:%c3"
+    for (int kk = 0; kk < NV_KS; ++kk)                       // ONE address register per chain: the K-steps are immediates
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\t"
+                     "ds_read_b64_tr_b16 %1, %2 offset:%c4"
                      : "=&v"(fa[kk]), "=&v"(fb[kk])
-                     : "v"(addr + kk * 16 * PITCH), "i"(4 * PITCH)
+                     : "v"(addr), "i"(OFS + kk * 16 * PITCH), "i"(OFS + kk * 16 * PITCH + 4 * PITCH)
                      : "memory");
 }
 __device__ __forceinline__ void nv_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -694,31 +703,39 @@ __device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i 
         bfr[kk] = v4i{fa[kk][0], fa[kk][1], fb[kk][0], fb[kk][1]};
     }
 }
+__device__ __forceinline__ long long nv_pack64(unsigned lo, unsigned hi) { return (long long)(((unsigned long long)hi << 32) | lo); }
 
-// NT = update plane tiles per level (8 planes each), NST = 16-byte staging chunks per thread, MINB = workgroups per CU
-template <int NL, int NT, int NST, int MINB>
+// MINB = workgroups per CU the register budget is set for (3: 168 VGPRs)
+template <int NL, int MINB>
 __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials,
     void *__restrict__ raster, int raster_u8, int nt_flag) {
     const bool nt_loads = __builtin_amdgcn_readfirstlane(nt_flag) != 0;
-    constexpr int TILE_B = (NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END) + 512;   // + room for the over-reads of unused columns
-    __shared__ __attribute__((aligned(16))) unsigned char s_tile[TILE_B];
-    __shared__ __attribute__((aligned(16))) int2 s_part[4][NL - 1][8][16];   // [wave][level - 1][cluster][parent] = (U, R2)
-    __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
-    __shared__ long long s_const[16];
-    __shared__ __attribute__((aligned(16))) v4i s_apat[NL][NV_KS][64];  // assign A fragments per level (lane-linear; used once per tile)
-    __shared__ int s_cnt[4][4][16];                                     // [wave][pixel group][cluster] voting pixels
-    __shared__ long long s_nj[16];
+    // LDS, one carve-up: [tile as in HBM, rows padded | (U, R2) tables | assign A fragments | labels | key bases | n_j].
+    // The transposed reads of level 3 run up to 64 bytes past the tile (unused columns): they land in the tables.
+    constexpr int TILE_B = NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END;
+    constexpr int PART_O = TILE_B, APAT_O = PART_O + 4 * NV_PART_W * 8, LAB_O = APAT_O + NL * NV_KS * NV_APAT_SLOTS * 16;
+    constexpr int CONST_O = LAB_O + KP_TP, NJ_O = CONST_O + 16 * 8, LDS_B = NJ_O + 16 * 8;
+    static_assert(MINB * ((LDS_B + 1279) / 1280) <= 128, "LDS: gfx950 allocates 160 KB in 1280-byte granules");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_B];
+    unsigned char *const s_tile = s_mem;
+    v4i *const s_apat = reinterpret_cast<v4i *>(s_mem + APAT_O);             // [level][K-step][slot]
+    unsigned char *const s_lab = s_mem + LAB_O;
+    long long *const s_const = reinterpret_cast<long long *>(s_mem + CONST_O);
+    long long *const s_nj = reinterpret_cast<long long *>(s_mem + NJ_O);
 
+    typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
+    typedef __attribute__((address_space(3))) unsigned char *lds_uchar_ptr;
     const bool do_acc = partials != nullptr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // grid (B, parts): workgroups are dispatched part-major, so the parts_eff * B working ones are the first to start
     const int b = blockIdx.x, part = blockIdx.y, nb = (int)gridDim.x;
     const int D = lo.D, D1 = D + 1;
     const uint16_t *cset = cent + (size_t)(per_image ? b : 0) * K * D;
     const int ntiles = lo.ntiles;
-    const bool working = part < parts_eff;                   // 2 workgroups per CU are resident: the others only emit zeros
+    const bool working = part < parts_eff;                   // MINB workgroups per CU are resident: the others only emit zeros
     const int nimg = per_image ? 1 : nb;
     const int G = parts_eff * nimg, g = per_image ? part : part * nb + b;
     const int nlist = ntiles * nimg;
@@ -733,6 +750,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
 
     // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
+    static_assert(8 * 4 * NV_DL * 2 <= TILE_B, "centroid scratch exceeds the tile buffer");
     for (int i = tid; i < 8 * 4 * NV_DL; i += 256) {
         const int j = i / (4 * NV_DL), L = (i / NV_DL) & 3, pl = i % NV_DL;
         const bool ok = j < K && L < NL && pl < lo.DL[L];
@@ -765,8 +783,10 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         }
     }
     // ---- assign A fragments per level: row r = 4*jj + pat (cluster jj), k-slot (h, t) of K-step kk = (plane 16*kk + 8*h + t/2,
-    //      byte t&1) of the level; patterns LL / M / HH as in kmeans_pass_mfma_kernel
-    {
+    //      byte t&1) of the level; patterns LL / M / HH as in kmeans_pass_mfma_kernel. Row pattern 3 is all zero: the 16 lanes
+    //      that hold it read the one zero slot, the others slot (3 jj + pat) * 2 + h.
+    const int a_slot = (lane & 3) == 3 ? NV_APAT_SLOTS - 1 : (3 * ((lane & 31) >> 2) + (lane & 3)) * 2 + (lane >> 5);
+    if (wave == 0) {
         const int r = lane & 31, h = lane >> 5;
         const int jj = r >> 2, pat = r & 3;
         const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
@@ -779,15 +799,15 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 v4i f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] = (int)(__builtin_amdgcn_perm(0u, (unsigned)w[e], sel) & msk);
-                if (wave == 0) s_apat[L][kk][lane] = f;
+                if (pat < 3 || lane == 3) s_apat[(L * NV_KS + kk) * NV_APAT_SLOTS + a_slot] = f;   // (lane 3: pattern 3, f == 0)
             }
     }
     __syncthreads();                                   // scratch reads done: the tile buffer is free
-    v4i accu[NL][NT];
+    v4i accu[NL][NV_UT];
 #pragma unroll
     for (int L = 0; L < NL; ++L)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
+        for (int nt = 0; nt < NV_UT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
     int cntacc = 0;
 
     // ---- staging: chunk ci (16 bytes at byte 16*ci of the tile) keeps its place inside its level; level-0 and level-1
@@ -795,32 +815,39 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const int nchunk = lo.tile_bytes >> 4;
     const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
               c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
-    v4i st[NST];
-    int sdst[NST];
+    v4i st[NV_NST];
+    unsigned sadr[NV_NST];                                  // per chunk: LDS byte address << 16 | byte offset inside the tile (both < 65 536)
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
+    for (int i = 0; i < NV_NST; ++i) {
         const int ci = min(tid + 256 * i, nchunk - 1);
         int d;
         if (ci < c1s) d = (ci >> 5) * NV_P0 + (ci & 31) * 16;
         else if (ci < c2s) d = NV_OFF1 + ((ci - c1s) >> 3) * NV_P1 + ((ci - c1s) & 7) * 16;
         else if (ci < c3s) d = NV_OFF2 + (ci - c2s) * 16;
         else d = NV_OFF3 + (ci - c3s) * 16;
-        sdst[i] = (int)(size_t)&s_tile[d];
+        sadr[i] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
     }
-    auto stage_load = [&](int tile) {
-        const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
+    auto stage_load = [&](int tile) {                       // uniform 64-bit tile base + 32-bit lane offset
+        const unsigned char *tb = fb + (size_t)tile * lo.tile_bytes;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[min(tid + 256 * i, nchunk - 1)], nt_loads);
+        for (int i = 0; i < NV_NST; ++i) {
+            unsigned o = sadr[i] & 0xffffu;                 // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
+            asm volatile("" : "+v"(o));                     //  offsets, these spilled - and a reload inside the loop waits for vmcnt(0))
+            st[i] = kp_load(reinterpret_cast<const v4i *>(tb + o), nt_loads);
+        }
     };
-    typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     auto stage_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = st[i];
+        for (int i = 0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sadr[i] >> 16) = st[i];
     };
 
-    const int un = lane & 15, ug = lane >> 4;             // update operand coordinates: cluster / byte-plane column, pixel group
-    const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
-    const unsigned eqr = (unsigned)un * 0x01010101u;
+    // update operand coordinates: row um = 2 * cluster + byte, K-group ukg = pixel rows 2 ukg, 2 ukg + 1 of the block
+    const int um = lane & 15, ukg = lane >> 4;
+    // one-hot bytes (b0 b1 b2 b3) of four pixels -> K-slots (px, t): (b0 0 b1 0 | b2 0 b3 0) for the low-byte rows, shifted up one
+    // byte for the high-byte rows (v_perm: selectors 4 .. 7 = bytes of the zero operand). ONE register holds the row's personality:
+    // the selector for (b0, b1); the one for (b2, b3) is it ^ 0x02020202, the byte shift of the count operands (it & 4) << 1,
+    // and the cluster's compare pattern comes from the lane number (three invariants fewer than the tile loop can keep).
+    const unsigned uselA0 = (um & 1) ? 0x01040004u : 0x04010400u;
 
     auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
     int ltile = g;
@@ -835,6 +862,43 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         by = blk0 / lo.bx_n;
         bx = blk0 - by * lo.bx_n;
     }
+    // ---- LDS addresses as plain integers: every lane keeps ONE base per access pattern and everything else is an
+    //      immediate of the DS instruction (left to itself hipcc hoists one register per (level, cluster pair, K-step) out of the
+    //      tile loop: 30 more invariants than three workgroups per CU leave room for)
+    typedef __attribute__((address_space(3))) const v4i *lds_cv4i;
+    typedef __attribute__((address_space(3))) const v2i *lds_cv2i;
+    typedef __attribute__((address_space(3))) v2i *lds_v2i;
+    typedef __attribute__((address_space(3))) const long long *lds_ci64;
+    typedef __attribute__((address_space(3))) const unsigned *lds_cu32;
+    typedef __attribute__((address_space(3))) const uint16_t *lds_cu16;
+    typedef __attribute__((address_space(3))) unsigned char *lds_u8;
+    const unsigned L0 = (unsigned)(size_t)(lds_uchar_ptr)s_mem;            // LDS address of the carve-up
+    unsigned a_tr[4], a_apat, a_pw[3], a_pr[2], a_labw, a_labr, a_ub[4];
+    {
+        const int n = lane & 31, h = lane >> 5, i16 = lane & 15, pxblk = (lane >> 4) & 1;
+        const int rowq = 8 * h + (i16 >> 2), colq = 16 * pxblk + 4 * (i16 & 3);
+        // transposed reads. level 1: the block's 16 parents are columns 16*wave .. +15; level 2: its 4 parents are columns
+        // 4*wave .. +3 of the plane's 16; level 3: its parent is column `wave` of the plane's 4 (the transpose read wants
+        // 8-byte-aligned column starts, so these two read the whole plane row)
+        a_tr[0] = L0 + rowq * NV_P0 + (wave * 64 + colq) * 2;
+        a_tr[1] = L0 + NV_OFF1 + rowq * NV_P1 + (16 * wave + colq) * 2;
+        a_tr[2] = L0 + NV_OFF2 + rowq * NV_P2 + colq * 2;
+        a_tr[3] = L0 + NV_OFF3 + rowq * NV_P3 + colq * 2;
+        a_apat = L0 + APAT_O + a_slot * 16;
+        // the wave's (U, R2) table: [cluster][16] level 1 | 128 + [cluster][4] level 2 | 160 + [cluster] level 3; cluster 2 gq + h
+        const unsigned pw = L0 + PART_O + wave * NV_PART_W * 8;
+        a_pw[0] = pw + (h * 16 + (n & 15)) * 8;
+        a_pw[1] = pw + (128 + h * 4 + (n & 3)) * 8;
+        a_pw[2] = pw + (160 + h) * 8;
+        a_pr[0] = pw + (h * 16 + (n >> 4) * 4 + ((n & 7) >> 1)) * 8;       // sub-tile 0; sub-tile 1: 8 parents on
+        a_pr[1] = pw + (128 + h * 4 + ((n & 7) >> 2)) * 8;                 // sub-tile 1: 2 parents on
+        a_labw = L0 + LAB_O + wave * 64 + n;
+        a_labr = L0 + LAB_O + wave * 64 + 16 * ukg;
+        a_ub[0] = L0 + um * NV_P0 + (wave * 64 + 16 * ukg) * 2;
+        a_ub[1] = L0 + NV_OFF1 + um * NV_P1 + (wave * 16 + 4 * ukg) * 2;
+        a_ub[2] = L0 + NV_OFF2 + um * NV_P2 + (wave * 4 + (ukg >> 1) * 2) * 2;
+        a_ub[3] = L0 + NV_OFF3 + um * NV_P3 + wave * 2;
+    }
     for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
         stage_write();
@@ -845,81 +909,65 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
 
         const int blk = 4 * tin + wave;
         const int n = lane & 31, h = lane >> 5;
-        const int i16 = lane & 15, pxblk = (lane >> 4) & 1;
-        // -------- assign. All transpose reads of the tile go out first (coarse levels, then both level-0 sub-tiles), one wait.
-        // level 1: the block's 16 parents are columns 16*wave .. +15; level 2: its 4 parents are columns 4*wave .. +3 of
-        // the plane's 16; level 3: its parent is column `wave` of the plane's 4 (the transpose read wants 8-byte-aligned
-        // column starts, so these two read the whole plane row)
-        v2i ca[3][NV_KS], cb[3][NV_KS], fa0[2][NV_KS], fb0[2][NV_KS];
-        const int rowq = 8 * h + (i16 >> 2), colq = 16 * pxblk + 4 * (i16 & 3);
-        if (NL > 1) nv_issue<NV_P1>((unsigned)(size_t)&s_tile[NV_OFF1 + rowq * NV_P1 + (16 * wave + colq) * 2], ca[0], cb[0]);
-        if (NL > 2) nv_issue<NV_P2>((unsigned)(size_t)&s_tile[NV_OFF2 + rowq * NV_P2 + colq * 2], ca[1], cb[1]);
-        if (NL > 3) nv_issue<NV_P3>((unsigned)(size_t)&s_tile[NV_OFF3 + rowq * NV_P3 + colq * 2], ca[2], cb[2]);
-        nv_wait();
-        // coarse levels: (U, R2) per cluster and parent of this wave's block -> s_part[wave]
+        // -------- assign
+        // Software pipeline over the five MFMA chains of a tile (levels 1 .. NL-1, then the two 32-pixel sub-tiles of level 0):
+        // the transposed reads of chain c + 1 go out before the MFMAs of chain c, one chain's fragments in flight at a time
+        // (all of them at once: 36 more VGPRs than three workgroups per CU leave).
+        v2i fa[2][NV_KS], fbv[2][NV_KS];
+        auto issue_chain = [&](int c, v2i (&xa)[NV_KS], v2i (&xb)[NV_KS]) {     // c = 0 .. NL-2: level c + 1; NL-1, NL: sub-tiles
+            if (c == 0 && NL > 1) nv_issue<NV_P1>(a_tr[1], xa, xb);
+            else if (c == 1 && NL > 2) nv_issue<NV_P2>(a_tr[2], xa, xb);
+            else if (c == 2 && NL > 3) nv_issue<NV_P3>(a_tr[3], xa, xb);
+            else if (c == NL - 1) nv_issue<NV_P0>(a_tr[0], xa, xb);
+            else nv_issue<NV_P0, 64>(a_tr[0], xa, xb);
+        };
+        auto apat = [&](int L, int kk) { return *reinterpret_cast<lds_cv4i>(a_apat + (L * NV_KS + kk) * NV_APAT_SLOTS * 16); };
+        issue_chain(0, fa[0], fbv[0]);
+        // coarse levels: (U, R2) per cluster and parent of this wave's block -> the wave's table
 #pragma unroll
         for (int L = 1; L < NL; ++L) {
             v4i bfr[NV_KS];
-            nv_take(ca[L - 1], cb[L - 1], bfr);
-            if (L == NL - 1)                                    // the level-0 reads travel while the last coarse chain runs
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-                    nv_issue<NV_P0>((unsigned)(size_t)&s_tile[rowq * NV_P0 + (wave * 64 + sub * 32 + colq) * 2], fa0[sub], fb0[sub]);
+            nv_wait();
+            nv_take(fa[(L - 1) & 1], fbv[(L - 1) & 1], bfr);
+            issue_chain(L, fa[L & 1], fbv[L & 1]);
             v16i acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0;
 #pragma unroll
-            for (int kk = 0; kk < NV_KS; ++kk)
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_apat[L][kk][lane], bfr[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < NV_KS; ++kk) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat(L, kk), bfr[kk], acc, 0, 0, 0);
             const bool keep = L == 1 ? n < 16 : L == 2 ? (n >> 2) == wave : n == wave;
-            const int pidx = L == 1 ? (n & 15) : L == 2 ? (n & 3) : 0;
+            const int cstride = L == 1 ? 32 : L == 2 ? 8 : 2;          // two clusters on
             if (keep)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
-                    s_part[wave][L - 1][2 * gq + h][pidx] = int2{__mul24(acc[4 * gq + 1], 256) + acc[4 * gq], acc[4 * gq + 2]};
+                    *reinterpret_cast<lds_v2i>(a_pw[L - 1] + gq * cstride * 8) =
+                        v2i{__mul24(acc[4 * gq + 1], 256) + acc[4 * gq], acc[4 * gq + 2]};
         }
-        // level 0: two 32-pixel sub-tiles (rows 4*sub .. 4*sub+3 of the block), both chains interleaved
-        v16i acc0[2];
-        {
-            v4i bfr[2][NV_KS];
-            nv_wait();
-            nv_take(fa0[0], fb0[0], bfr[0]);
-            nv_take(fa0[1], fb0[1], bfr[1]);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc0[sub][e] = 0;
-#pragma unroll
-            for (int kk = 0; kk < NV_KS; ++kk) {
-                const v4i a0 = s_apat[0][kk][lane];
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-                    acc0[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bfr[sub][kk], acc0[sub], 0, 0, 0);
-            }
-        }
+        // level 0: two 32-pixel sub-tiles (rows 4*sub .. 4*sub+3 of the block), one after the other
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            const int pl = wave * 64 + sub * 32 + n;
-            const int yi = 4 * sub + (n >> 3), xi = n & 7;      // pixel inside the block
-            const int p1 = (yi >> 1) * 4 + (xi >> 1), p2 = (yi >> 2) * 2 + (xi >> 2);
-            int2 cp[3][4];                                       // the coarse parts of this pixel's four clusters: loads first
+            v16i acc0;
+            {
+                const int c = NL - 1 + sub;
+                v4i bfr[NV_KS];
+                nv_wait();
+                nv_take(fa[c & 1], fbv[c & 1], bfr);                          // chain c travels in buffer c & 1
+                if (sub == 0) issue_chain(c + 1, fa[(c + 1) & 1], fbv[(c + 1) & 1]);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (NL > 1) cp[0][gq] = s_part[wave][0][2 * gq + h][p1];
-                if (NL > 2) cp[1][gq] = s_part[wave][1][2 * gq + h][p2];
-                if (NL > 3) cp[2][gq] = s_part[wave][2][2 * gq + h][0];
+                for (int e = 0; e < 16; ++e) acc0[e] = 0;
+#pragma unroll
+                for (int kk = 0; kk < NV_KS; ++kk) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(apat(0, kk), bfr[kk], acc0, 0, 0, 0);
             }
             long long best = 0x7fffffffffffffffLL;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int j = 2 * gq + h;
-                int u = __mul24(acc0[sub][4 * gq + 1], 256) + acc0[sub][4 * gq], r2v = acc0[sub][4 * gq + 2];
-#pragma unroll
-                for (int L = 1; L < NL; ++L) {
-                    u += cp[L - 1][gq].x;
-                    r2v += cp[L - 1][gq].y;
-                }
-                long long key = mad_i64_i32(u, -32, s_const[j]);
+                int u = __mul24(acc0[4 * gq + 1], 256) + acc0[4 * gq], r2v = acc0[4 * gq + 2];
+                if (NL > 1) { const v2i c = *reinterpret_cast<lds_cv2i>(a_pr[0] + gq * 256 + sub * 64); u += c[0]; r2v += c[1]; }
+                if (NL > 2) { const v2i c = *reinterpret_cast<lds_cv2i>(a_pr[1] + gq * 64 + sub * 16); u += c[0]; r2v += c[1]; }
+                if (NL > 3) { const v2i c = *reinterpret_cast<lds_cv2i>(a_pw[2] + gq * 16); u += c[0]; r2v += c[1]; }
+                // key base of cluster 2 gq + h: a broadcast read (uniform address per half wave)
+                const long long kb = *reinterpret_cast<lds_ci64>(L0 + CONST_O + gq * 16 + h * 8);
+                long long key = mad_i64_i32(u, -32, kb);
                 key = mad_i64_i32(r2v, -2097152, key);
                 best = key < best ? key : best;
             }
@@ -930,6 +978,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
             const int bj = (int)((pb < best ? pb : best) & 15);
             if (h == 0) {
+                const int yi = 4 * sub + (n >> 3), xi = n & 7;               // pixel inside the block
                 int y = 8 * by + yi, x = 8 * bx + xi, xlim = lo.W;          // see kmeans_pass_mfma_kernel
                 if (NL <= 2 && blk >= lo.nmain) {               // (deeper banks have main blocks only)
                     int no = n;
@@ -938,7 +987,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 }
                 const bool inimg = blk < lo.nblk && y < lo.H && x < xlim;
                 const bool valid = inimg && y >= row_lo && y < row_hi;
-                s_lab[pl] = valid ? (unsigned char)bj : (unsigned char)0xFF;
+                *reinterpret_cast<lds_u8>(a_labw + sub * 32) = valid ? (unsigned char)bj : (unsigned char)0xFF;
                 if (raster && inimg) {                        // raster label map (see kmeans_pass_mfma_kernel)
                     const size_t o = ((size_t)(per_image ? b : tile / ntiles) * lo.H + y) * lo.W + x;
                     if (raster_u8) static_cast<uint8_t *>(raster)[o] = (uint8_t)bj;
@@ -946,17 +995,14 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 }
             }
         }
-        // -------- update (the block's labels were written by this wave: no barrier). Operand loads of a level go out together.
+        // -------- update (the block's labels were written by this wave: no barrier)
         if (do_acc) {
-            const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
-            const int dq = un >> 1;                             // plane inside a tile of 8
-            v2i w1[NT];
-            unsigned w2[NT], w3[NT];
-            if (NL > 1)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    w1[nt] = *reinterpret_cast<const v2i *>(&s_tile[NV_OFF1 + (8 * nt + dq) * NV_P1 + (wave * 16 + 4 * ug) * 2]);
-            v4i oh;                                              // byte 0x80 where label == un (pixels 16*ug .. +15 = rows 2ug, 2ug+1)
+            const v4i lw = *reinterpret_cast<lds_cv4i>(a_labr);   // labels of pixel rows 2 ukg (bytes 0-7), 2 ukg + 1
+            unsigned uselA = uselA0, lno = (unsigned)lane;
+            asm volatile("" : "+v"(uselA), "+v"(lno));            // (opaque: what follows is recomputed per tile, not hoisted)
+            const unsigned uselB = uselA ^ 0x02020202u, ush = (uselA & 4u) << 1;
+            const unsigned eqr = ((lno >> 1) & 7u) * 0x01010101u;
+            v4i oh;                                              // byte 0x80 where label == this row's cluster
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned x = (unsigned)lw[i] ^ eqr;
@@ -965,65 +1011,47 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             }
             cntacc += __builtin_popcount((unsigned)oh[0]) + __builtin_popcount((unsigned)oh[1]) +
                       __builtin_popcount((unsigned)oh[2]) + __builtin_popcount((unsigned)oh[3]);
-            // level 0: one-hot digit -128 over the 64 pixels, three plane tiles at a time
+            // level 0: half hf = pixel row 2 ukg + hf of the block for this K-group; K-slot 2 q + t = (pixel q of the row, byte t)
 #pragma unroll
-            for (int base = 0; base < NT; base += 3) {
-                constexpr int GRP = 3;
-                v4i w0a[GRP], w0b[GRP];
+            for (int hf = 0; hf < 2; ++hf) {
+                v4i a0;
+                a0[0] = (int)__builtin_amdgcn_perm(0u, (unsigned)oh[2 * hf], uselA);
+                a0[1] = (int)__builtin_amdgcn_perm(0u, (unsigned)oh[2 * hf], uselB);
+                a0[2] = (int)__builtin_amdgcn_perm(0u, (unsigned)oh[2 * hf + 1], uselA);
+                a0[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)oh[2 * hf + 1], uselB);
 #pragma unroll
-                for (int q = 0; q < GRP; ++q)
-                    if (base + q < NT) {
-                        const v4i *src = reinterpret_cast<const v4i *>(&s_tile[(8 * (base + q) + dq) * NV_P0 + (wave * 64 + 16 * ug) * 2]);
-                        w0a[q] = src[0];
-                        w0b[q] = src[1];
-                    }
-#pragma unroll
-                for (int q = 0; q < GRP; ++q)
-                    if (base + q < NT) {
-                        v4i bq;
-                        bq[0] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][1], (unsigned)w0a[q][0], usel);
-                        bq[1] = (int)__builtin_amdgcn_perm((unsigned)w0a[q][3], (unsigned)w0a[q][2], usel);
-                        bq[2] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][1], (unsigned)w0b[q][0], usel);
-                        bq[3] = (int)__builtin_amdgcn_perm((unsigned)w0b[q][3], (unsigned)w0b[q][2], usel);
-                        accu[0][base + q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq, accu[0][base + q], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NV_UT; ++nt) {
+                    const v4i bq = *reinterpret_cast<lds_cv4i>(a_ub[0] + nt * 16 * NV_P0 + hf * 16);
+                    accu[0][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bq, accu[0][nt], 0, 0, 0);
+                }
             }
-            if (NL > 2)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    w2[nt] = *reinterpret_cast<const unsigned *>(&s_tile[NV_OFF2 + (8 * nt + dq) * NV_P2 + (wave * 4 + (ug >> 1) * 2) * 2]);
-            if (NL > 3)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    w3[nt] = *reinterpret_cast<const uint16_t *>(&s_tile[NV_OFF3 + (8 * nt + dq) * NV_P3 + wave * 2]);
-            if (NL > 1) {
-                // counts of label un under the 4 level-1 parents of pixel rows 2ug, 2ug+1 (parent row ug, columns 0..3)
+            if constexpr (NL > 1) {
+                // counts of this row's label under the 4 level-1 parents of pixel rows 2 ukg, 2 ukg + 1 (parent row ukg, columns 0..3)
                 const unsigned e0 = (unsigned)oh[0] >> 7, e1 = (unsigned)oh[1] >> 7, e2 = (unsigned)oh[2] >> 7, e3 = (unsigned)oh[3] >> 7;
                 const unsigned sa = e0 + e2, sb = e1 + e3;       // bytes: columns 0..3 / 4..7, both rows
-                const unsigned ta = (sa & 0x00ff00ffu) + ((sa >> 8) & 0x00ff00ffu);   // parents 0 | 1 << 16
-                const unsigned tb = (sb & 0x00ff00ffu) + ((sb >> 8) & 0x00ff00ffu);   // parents 2 | 3 << 16
-                const unsigned c4 = __builtin_amdgcn_perm(tb, ta, 0x06040200u);       // bytes: parents 0, 1, 2, 3
-                const v4i a1 = v4i{(int)c4, 0, 0, 0};
+                const unsigned ta = (sa & 0x00ff00ffu) + ((sa >> 8) & 0x00ff00ffu);   // bytes (c0 0 c1 0): K-slots (parent 0, lo) (0, hi) (1, lo) (1, hi)
+                const unsigned tb = (sb & 0x00ff00ffu) + ((sb >> 8) & 0x00ff00ffu);   // parents 2, 3
+                const long long a1 = nv_pack64(ta << ush, tb << ush);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const v4i bq = v4i{(int)__builtin_amdgcn_perm((unsigned)w1[nt][1], (unsigned)w1[nt][0], usel), 0, 0, 0};
-                    accu[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bq, accu[1][nt], 0, 0, 0);
+                for (int nt = 0; nt < NV_UT; ++nt) {
+                    const v2i w = *reinterpret_cast<lds_cv2i>(a_ub[1] + nt * 16 * NV_P1);
+                    accu[1][nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, nv_pack64((unsigned)w[0], (unsigned)w[1]), accu[1][nt], 0, 0, 0);
                 }
-                if (NL > 2) {
-                    // level 2: k-slots (ug, left / right half): partial counts of the parent (ug >> 1, half)
+                if constexpr (NL > 2) {
+                    // level 2: this K-group's partial counts of the parents (ukg >> 1, 0 / 1): K-slots (parent column, byte)
                     const unsigned cl = (ta & 0xffu) + (ta >> 16), cr = (tb & 0xffu) + (tb >> 16);
-                    const v4i a2 = v4i{(int)(cl | (cr << 8)), 0, 0, 0};
+                    const long long a2 = nv_pack64((cl | (cr << 16)) << ush, 0u);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const v4i bq = v4i{(int)__builtin_amdgcn_perm(w2[nt], w2[nt], usel), 0, 0, 0};
-                        accu[2][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, bq, accu[2][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NV_UT; ++nt) {
+                        const unsigned w = *reinterpret_cast<lds_cu32>(a_ub[2] + nt * 16 * NV_P2);
+                        accu[2][nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a2, nv_pack64(w, 0u), accu[2][nt], 0, 0, 0);
                     }
-                    if (NL > 3) {
-                        const v4i a3 = v4i{(int)(cl + cr), 0, 0, 0};     // level 3: k-slot ug, the block's one parent
+                    if constexpr (NL > 3) {
+                        const long long a3 = nv_pack64((cl + cr) << ush, 0u);   // level 3: the block's one parent
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const v4i bq = v4i{(int)((un & 1) ? (w3[nt] >> 8) : (w3[nt] & 255u)), 0, 0, 0};
-                            accu[3][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, bq, accu[3][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NV_UT; ++nt) {
+                            const unsigned w = *reinterpret_cast<lds_cu16>(a_ub[3] + nt * 16 * NV_P3);
+                            accu[3][nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a3, nv_pack64(w, 0u), accu[3][nt], 0, 0, 0);
                         }
                     }
                 }
@@ -1049,25 +1077,26 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     }
     if (!do_acc) return;
 
-    // ---- fold: voting pixel counts first, then one level at a time through the tile buffer ([4 waves][16][96] ints)
-    s_cnt[wave][ug][un] = cntacc;
+    // ---- fold: voting pixel counts first, then one level at a time through the tile buffer ([4 waves][16 rows][48 planes] ints;
+    //      row 2 j + t = byte t of cluster j)
+    constexpr int RW = NV_UT * 16;
+    int *red = reinterpret_cast<int *>(s_tile);
+    int *s_cnt = red + 4 * 16 * RW;                               // [wave][K-group][row]
+    static_assert((4 * 16 * RW + 4 * 4 * 16) * 4 <= TILE_B, "fold scratch exceeds the tile buffer");
+    s_cnt[(wave * 4 + ukg) * 16 + um] = cntacc;
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 8) {
         long long c = 0;
-        for (int w = 0; w < 4; ++w)
-            for (int q = 0; q < 4; ++q) c += s_cnt[w][q][tid];
+        for (int w = 0; w < 16; ++w) c += s_cnt[w * 16 + 2 * tid];
         s_nj[tid] = c;
     }
-    constexpr int RW = NT * 16;
-    int *red = reinterpret_cast<int *>(s_tile);
-    static_assert(4 * 16 * RW * 4 <= TILE_B && 8 * 4 * NV_DL * 2 <= TILE_B, "fold / centroid scratch exceeds the tile buffer");
 #pragma unroll
     for (int L = 0; L < NL; ++L) {
         __syncthreads();                                          // previous level's reads (and s_nj) done
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NV_UT; ++nt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW + 16 * nt + un] = accu[L][nt][e];
+            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ukg + e) * RW + 16 * nt + um] = accu[L][nt][e];
         __syncthreads();
         const int DLv = lo.DL[L];
         for (int i = tid; i < K * DLv; i += 256) {
@@ -1075,8 +1104,8 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             long long flo = 0, fhi = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                flo += red[(w * 16 + j) * RW + 2 * pl];
-                fhi += red[(w * 16 + j) * RW + 2 * pl + 1];
+                flo += red[(w * 16 + 2 * j) * RW + pl];
+                fhi += red[(w * 16 + 2 * j + 1) * RW + pl];
             }
             if (L == 0) {                                         // the one-hot digit is -128
                 flo = -flo / 128;
@@ -1117,14 +1146,18 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, con
     return GCS_OK;
 }
 
-// Working workgroups per image of the native pass: two 4-wave workgroups per CU are resident, so at most 512 / B of the
-// `parts` workgroups of an image work (the others only write zero rows) - but never so few that a wave's int32 MFMA
-// accumulators can overflow: they are flushed only at the end of the pass, a voting pixel adds up to 128 * 128 to one of
-// them and a wave sees a quarter of its workgroup's pixels, so a workgroup may own at most 2^31 / 2^14 * 4 = 524 288 pixels;
-// the bound used is half of that. (`parts` itself keeps a workgroup below 65 536 pixels: gcs_kmeans_parts_per_image.)
+// Working workgroups per image of the native pass: GCS_NV_MINB (three) 4-wave workgroups per CU are resident, so at most
+// 256 * GCS_NV_MINB / B of the `parts` workgroups of an image work (the others only write zero rows) - but never so few that a
+// wave's int32 MFMA accumulators can overflow: they are flushed only at the end of the pass, a voting pixel adds up to 128 * 128
+// to one of them and a wave sees a quarter of its workgroup's pixels, so a workgroup may own at most 2^31 / 2^14 * 4 = 524 288
+// pixels; the bound used is half of that. (`parts` itself keeps a workgroup below 65 536 pixels: gcs_kmeans_parts_per_image.)
+#ifndef GCS_NV_MINB
+#define GCS_NV_MINB 3
+#endif
 constexpr long long NV_MAX_PX_PER_WORKGROUP = 262144;
 static int native_parts_eff(int B, int parts, long long px_image) {
-    int eff = 512 / B > 0 ? 512 / B : 1;
+    constexpr int slots = 256 * GCS_NV_MINB;
+    int eff = slots / B > 0 ? slots / B : 1;
     const long long need = (px_image + NV_MAX_PX_PER_WORKGROUP - 1) / NV_MAX_PX_PER_WORKGROUP;
     if (eff < need) eff = (int)need;
     return eff < parts ? eff : parts;
@@ -1178,16 +1211,16 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
                 else { GCS_KP_LAUNCH(2, 10, KP_DSTEPS_NARROW); }
             }
         } else if (k <= 8) {
-            bool native = nchunk <= 256 * 8 && lo.n_levels >= 2;          // every level at most 48 planes: levels at own resolution
+            bool native = nchunk <= 256 * NV_NST && lo.n_levels >= 2;          // every level at most 48 planes: levels at own resolution
             for (int L = 0; L < lo.n_levels; ++L) native = native && lo.DL[L] <= NV_DL;
 #ifdef GCS_KP_NO_NATIVE
             native = false;
 #endif
             if (native) {
-                // two 4-wave workgroups per CU are resident: 512 of the workgroups work, the others write zero partial rows
+                // GCS_NV_MINB 4-wave workgroups per CU are resident: that many work, the others write zero partial rows
                 const int parts_eff = native_parts_eff(B, parts, (long long)lo.ntiles * KP_TP);
 #define GCS_NV_LAUNCH(NL_)                                                                                                \
-    hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, 6, 8, 2>), dim3(B, parts), dim3(256), 0, stream,                   \
+    hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, GCS_NV_MINB>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
                        reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
                 if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
