@@ -677,7 +677,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 // Same tile list, sweep order, validity rules, outputs and partial layout as kmeans_pass_mfma_kernel.
 constexpr int NV_DL = 48, NV_KS = 3, NV_UT = 3;              // planes (LDS rows), assign K-steps and update plane tiles per level
 constexpr int NV_NST = 8;                                     // 16-byte staging chunks per thread (tile_bytes <= 32 768)
-constexpr int NV_P0 = KP_TP * 2 + 64, NV_P1 = 128 + 32, NV_P2 = 32, NV_P3 = 8;   // LDS bytes per plane row of level L
+constexpr int NV_P0 = KP_TP * 2, NV_P1 = 128 + 32, NV_P2 = 32, NV_P3 = 8;   // LDS bytes per plane row of level L
+// Level-0 rows carry no padding: the 16-byte chunk c of plane row r sits at chunk c ^ nv_swz(r) of its row. The transposed reads of
+// the assign phase (4 consecutive rows x 64 bytes per half wave) and the operand reads of the update phase (16 consecutive rows, one
+// chunk each) then both touch 16 distinct chunk columns = all 64 banks once (with padded rows the update reads of rows r, r + 4, r + 8,
+// r + 12 shared their banks: SQ_LDS_BANK_CONFLICT 31.7 M cycles per launch). The staging writes place chunks by table anyway.
+__host__ __device__ constexpr int nv_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 constexpr int NV_OFF1 = NV_DL * NV_P0, NV_OFF2 = NV_OFF1 + NV_DL * NV_P1, NV_OFF3 = NV_OFF2 + NV_DL * NV_P2;
 constexpr int NV_END = NV_OFF3 + NV_DL * NV_P3;
 constexpr int NV_PART_W = 8 * (16 + 4 + 1);                  // (U, R2) pairs per wave: [cluster][16 | 4 | 1 parents of level 1 | 2 | 3]
@@ -695,6 +700,16 @@ __device__ __forceinline__ void nv_issue(unsigned addr, v2i (&fa)[NV_KS], v2i (&
                      : "v"(addr), "i"(OFS + kk * 16 * PITCH), "i"(OFS + kk * 16 * PITCH + 4 * PITCH)
                      : "memory");
 }
+// level 0: the two reads of a K-step have bases of their own (swizzled rows)
+__device__ __forceinline__ void nv_issue0(unsigned addr_a, unsigned addr_b, v2i (&fa)[NV_KS], v2i (&fb)[NV_KS]) {
+#pragma unroll
+    for (int kk = 0; kk < NV_KS; ++kk)
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\t"
+                     "ds_read_b64_tr_b16 %1, %3 offset:%c4"
+                     : "=&v"(fa[kk]), "=&v"(fb[kk])
+                     : "v"(addr_a), "v"(addr_b), "i"(kk * 16 * NV_P0)
+                     : "memory");
+}
 __device__ __forceinline__ void nv_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i (&bfr)[NV_KS]) {
 #pragma unroll
@@ -705,8 +720,8 @@ __device__ __forceinline__ void nv_take(v2i (&fa)[NV_KS], v2i (&fb)[NV_KS], v4i 
 }
 __device__ __forceinline__ long long nv_pack64(unsigned lo, unsigned hi) { return (long long)(((unsigned long long)hi << 32) | lo); }
 
-// MINB = workgroups per CU the register budget is set for (3: 168 VGPRs)
-template <int NL, int MINB>
+// MINB = workgroups per CU the register budget is set for (3: 168 VGPRs); N0 = staging rounds wholly inside level 0 (see staging)
+template <int NL, int MINB, int N0>
 __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials,
@@ -815,30 +830,40 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const int nchunk = lo.tile_bytes >> 4;
     const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
               c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
+    // Rounds i < N0 lie wholly inside level 0 (N0 = 6 for the 48-plane level 0 of every bank with 8 orientations, else 0): chunk
+    // tid + 256 i is 16 bytes at offset 16 tid + 4096 i of the tile, plane row (tid >> 5) + 8 i, whose swizzle is that of row tid >> 5
+    // ^ 2 for odd i - ONE address register for all of them, a scalar add on the tile base per round. The other rounds keep a table.
     v4i st[NV_NST];
-    unsigned sadr[NV_NST];                                  // per chunk: LDS byte address << 16 | byte offset inside the tile (both < 65 536)
+    unsigned sadr[NV_NST - N0];                             // per chunk: LDS byte address << 16 | byte offset inside the tile (both < 65 536)
+    const unsigned s0adr = (unsigned)(size_t)(lds_uchar_ptr)s_mem + (tid >> 5) * NV_P0 + (((tid & 31) ^ nv_swz(tid >> 5)) << 4);
 #pragma unroll
-    for (int i = 0; i < NV_NST; ++i) {
+    for (int i = N0; i < NV_NST; ++i) {
         const int ci = min(tid + 256 * i, nchunk - 1);
         int d;
-        if (ci < c1s) d = (ci >> 5) * NV_P0 + (ci & 31) * 16;
+        if (ci < c1s) d = (ci >> 5) * NV_P0 + ((ci & 31) ^ nv_swz(ci >> 5)) * 16;
         else if (ci < c2s) d = NV_OFF1 + ((ci - c1s) >> 3) * NV_P1 + ((ci - c1s) & 7) * 16;
         else if (ci < c3s) d = NV_OFF2 + (ci - c2s) * 16;
         else d = NV_OFF3 + (ci - c3s) * 16;
-        sadr[i] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
+        sadr[i - N0] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
     }
     auto stage_load = [&](int tile) {                       // uniform 64-bit tile base + 32-bit lane offset
         const unsigned char *tb = fb + (size_t)tile * lo.tile_bytes;
+        unsigned o0 = (unsigned)tid * 16u;
+        asm volatile("" : "+v"(o0));                        // (opaque: see below)
 #pragma unroll
-        for (int i = 0; i < NV_NST; ++i) {
-            unsigned o = sadr[i] & 0xffffu;                 // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
+        for (int i = 0; i < N0; ++i) st[i] = kp_load(reinterpret_cast<const v4i *>(tb + i * 4096 + o0), nt_loads);
+#pragma unroll
+        for (int i = N0; i < NV_NST; ++i) {
+            unsigned o = sadr[i - N0] & 0xffffu;            // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
             asm volatile("" : "+v"(o));                     //  offsets, these spilled - and a reload inside the loop waits for vmcnt(0))
             st[i] = kp_load(reinterpret_cast<const v4i *>(tb + o), nt_loads);
         }
     };
     auto stage_write = [&]() {
 #pragma unroll
-        for (int i = 0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sadr[i] >> 16) = st[i];
+        for (int i = 0; i < N0; ++i) *reinterpret_cast<lds_v4i_ptr>((s0adr ^ ((i & 1) * 32u)) + i * 8 * NV_P0) = st[i];
+#pragma unroll
+        for (int i = N0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sadr[i - N0] >> 16) = st[i];
     };
 
     // update operand coordinates: row um = 2 * cluster + byte, K-group ukg = pixel rows 2 ukg, 2 ukg + 1 of the block
@@ -873,14 +898,18 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     typedef __attribute__((address_space(3))) const uint16_t *lds_cu16;
     typedef __attribute__((address_space(3))) unsigned char *lds_u8;
     const unsigned L0 = (unsigned)(size_t)(lds_uchar_ptr)s_mem;            // LDS address of the carve-up
-    unsigned a_tr[4], a_apat, a_pw[3], a_pr[2], a_labw, a_labr, a_ub[4];
+    unsigned a_tr[4], a_tr0b, a_apat, a_pw[3], a_pr[2], a_labw, a_labr, a_ub[4];
     {
         const int n = lane & 31, h = lane >> 5, i16 = lane & 15, pxblk = (lane >> 4) & 1;
         const int rowq = 8 * h + (i16 >> 2), colq = 16 * pxblk + 4 * (i16 & 3);
-        // transposed reads. level 1: the block's 16 parents are columns 16*wave .. +15; level 2: its 4 parents are columns
+        // transposed reads. level 0 (swizzled rows, see nv_swz): the first read of a K-step takes rows rowq + 16 kk, the second rows
+        // + 4 - their chunk columns differ (nv_swz(r + 4) = nv_swz(r) ^ 1), hence two bases; sub-tile 1 = both ^ 64.
+        // level 1: the block's 16 parents are columns 16*wave .. +15; level 2: its 4 parents are columns
         // 4*wave .. +3 of the plane's 16; level 3: its parent is column `wave` of the plane's 4 (the transpose read wants
         // 8-byte-aligned column starts, so these two read the whole plane row)
-        a_tr[0] = L0 + rowq * NV_P0 + (wave * 64 + colq) * 2;
+        const int c0 = wave * 8 + 2 * pxblk + ((i16 & 3) >> 1);
+        a_tr[0] = rowq * NV_P0 + ((c0 ^ nv_swz(rowq)) << 4) + (i16 & 1) * 8;
+        a_tr0b = (rowq + 4) * NV_P0 + ((c0 ^ nv_swz(rowq + 4)) << 4) + (i16 & 1) * 8;
         a_tr[1] = L0 + NV_OFF1 + rowq * NV_P1 + (16 * wave + colq) * 2;
         a_tr[2] = L0 + NV_OFF2 + rowq * NV_P2 + colq * 2;
         a_tr[3] = L0 + NV_OFF3 + rowq * NV_P3 + colq * 2;
@@ -894,7 +923,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         a_pr[1] = pw + (128 + h * 4 + ((n & 7) >> 2)) * 8;                 // sub-tile 1: 2 parents on
         a_labw = L0 + LAB_O + wave * 64 + n;
         a_labr = L0 + LAB_O + wave * 64 + 16 * ukg;
-        a_ub[0] = L0 + um * NV_P0 + (wave * 64 + 16 * ukg) * 2;
+        a_ub[0] = um * NV_P0 + (((wave * 8 + 2 * ukg) ^ nv_swz(um)) << 4);          // pixel row 2 ukg of the block; row 2 ukg + 1: ^ 16
         a_ub[1] = L0 + NV_OFF1 + um * NV_P1 + (wave * 16 + 4 * ukg) * 2;
         a_ub[2] = L0 + NV_OFF2 + um * NV_P2 + (wave * 4 + (ukg >> 1) * 2) * 2;
         a_ub[3] = L0 + NV_OFF3 + um * NV_P3 + wave * 2;
@@ -918,8 +947,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             if (c == 0 && NL > 1) nv_issue<NV_P1>(a_tr[1], xa, xb);
             else if (c == 1 && NL > 2) nv_issue<NV_P2>(a_tr[2], xa, xb);
             else if (c == 2 && NL > 3) nv_issue<NV_P3>(a_tr[3], xa, xb);
-            else if (c == NL - 1) nv_issue<NV_P0>(a_tr[0], xa, xb);
-            else nv_issue<NV_P0, 64>(a_tr[0], xa, xb);
+            else nv_issue0(L0 + (a_tr[0] ^ (c == NL - 1 ? 0u : 64u)), L0 + (a_tr0b ^ (c == NL - 1 ? 0u : 64u)), xa, xb);
         };
         auto apat = [&](int L, int kk) { return *reinterpret_cast<lds_cv4i>(a_apat + (L * NV_KS + kk) * NV_APAT_SLOTS * 16); };
         issue_chain(0, fa[0], fbv[0]);
@@ -1021,7 +1049,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 a0[3] = (int)__builtin_amdgcn_perm(0u, (unsigned)oh[2 * hf + 1], uselB);
 #pragma unroll
                 for (int nt = 0; nt < NV_UT; ++nt) {
-                    const v4i bq = *reinterpret_cast<lds_cv4i>(a_ub[0] + nt * 16 * NV_P0 + hf * 16);
+                    const v4i bq = *reinterpret_cast<lds_cv4i>(L0 + (a_ub[0] ^ (hf * 16u)) + nt * 16 * NV_P0);
                     accu[0][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bq, accu[0][nt], 0, 0, 0);
                 }
             }
@@ -1155,8 +1183,8 @@ static int launch_assign(const uint16_t *feats, const uint16_t *cent, int B, con
 #define GCS_NV_MINB 3
 #endif
 constexpr long long NV_MAX_PX_PER_WORKGROUP = 262144;
-static int native_parts_eff(int B, int parts, long long px_image) {
-    constexpr int slots = 256 * GCS_NV_MINB;
+static int native_parts_eff(int B, int parts, long long px_image, int minb = GCS_NV_MINB) {
+    const int slots = 256 * minb;
     int eff = slots / B > 0 ? slots / B : 1;
     const long long need = (px_image + NV_MAX_PX_PER_WORKGROUP - 1) / NV_MAX_PX_PER_WORKGROUP;
     if (eff < need) eff = (int)need;
@@ -1218,15 +1246,24 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
 #endif
             if (native) {
                 // GCS_NV_MINB 4-wave workgroups per CU are resident: that many work, the others write zero partial rows
-                const int parts_eff = native_parts_eff(B, parts, (long long)lo.ntiles * KP_TP);
-#define GCS_NV_LAUNCH(NL_)                                                                                                \
-    hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, GCS_NV_MINB>), dim3(B, parts), dim3(256), 0, stream,                   \
+                // (four levels whose level 0 has fewer than 48 planes keep all eight staging addresses in a table: that variant
+                // does not fit 168 VGPRs and runs with two workgroups per CU)
+                const int minb = lo.n_levels == 4 && lo.DL[0] != NV_DL ? 2 : GCS_NV_MINB;
+                const int parts_eff = native_parts_eff(B, parts, (long long)lo.ntiles * KP_TP, minb);
+#define GCS_NV_LAUNCH_(NL_, MINB_, N0_)                                                                                       \
+    hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, MINB_, N0_>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
                        reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
-                if (lo.n_levels == 2) GCS_NV_LAUNCH(2);
-                else if (lo.n_levels == 3) GCS_NV_LAUNCH(3);
-                else GCS_NV_LAUNCH(4);
+#define GCS_NV_LAUNCH(NL_, MINB0_)                                          \
+    do {                                                                    \
+        if (lo.DL[0] == NV_DL) GCS_NV_LAUNCH_(NL_, GCS_NV_MINB, 6);         \
+        else GCS_NV_LAUNCH_(NL_, MINB0_, 0);                                \
+    } while (0)
+                if (lo.n_levels == 2) GCS_NV_LAUNCH(2, GCS_NV_MINB);
+                else if (lo.n_levels == 3) GCS_NV_LAUNCH(3, GCS_NV_MINB);
+                else GCS_NV_LAUNCH(4, 2);
 #undef GCS_NV_LAUNCH
+#undef GCS_NV_LAUNCH_
             }
             // pyramid banks (config 4: 2 040 chunks per tile) fit 5 chunks per thread of an 8-wave workgroup without spills
             else if ((nchunk + 511) / 512 <= 5) { GCS_KP_LAUNCHW(1, 5, KP_DSTEPS_WIDE, 8); }

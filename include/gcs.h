@@ -128,7 +128,8 @@ int gcs_kmeans_assign_accumulate(const uint16_t *feats_dev, const uint16_t *cent
  * written straight in raster order, out_dev [B][H][W] int32 (out_u8 == 0: what metrics.py:43-51 consumes) or uint8
  * (out_u8 != 0). Same result as gcs_kmeans_assign_accumulate(labels, NULL) (followed by gcs_labels_widen for int32).
  * scratch_labels_dev: a uint8 label map (gcs_label_slab_bytes) that is needed, and then also filled, only for int32 output of
- * feature vectors of 208 or more planes (the generic pass); may be NULL otherwise. Whole images only (no row window). */
+ * feature vectors of 208 or more planes (the generic pass); may be NULL otherwise - for D <= 207 it is never written, even when
+ * passed. Whole images only (no row window). */
 int gcs_kmeans_assign_raster(const uint16_t *feats_dev, const uint16_t *centroids_dev, int B, int H, int W, int n_scales,
                              int n_orient, int k, int n_sets, int reverse, void *out_dev, int out_u8,
                              uint8_t *scratch_labels_dev, gcs_stream_t stream);
@@ -157,8 +158,10 @@ int gcs_labels_widen(const uint8_t *labels_dev, int B, int H, int W, int32_t *ou
  * exact integer square root and its biased form in the epilogue (SPEC.md §3: n <= 2 * 32767^2 < 2^31, guaranteed by the
  * tap-sum bound of gcs_bank_pack) is wrong. Expected 0. */
 int gcs_selftest_isqrt(unsigned n_max, unsigned *bad_dev, gcs_stream_t stream);
-/* Test hook (host only): working workgroups per image of the deep-bank Lloyd pass for a batch shape; B * H * W / that
- * many pixels per workgroup must stay below the int32 accumulator bound (262 144 pixels). 0 for a bad shape. */
+/* Test hook (host only): working workgroups per image of the deep-bank Lloyd pass for a batch shape, computed from the
+ * shape's tile count WITHOUT packed edge strips (an upper bound of every bank's tile count; the launcher uses the bank's own
+ * count, which can only lower the pixels per workgroup); B * H * W / that many pixels per workgroup must stay below the
+ * int32 accumulator bound (262 144 pixels). 0 for a bad shape. */
 int gcs_selftest_native_parts(int B, int H, int W);
 
 /* ---- boundary scoring of one image -------------------------------------- */

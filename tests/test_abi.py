@@ -174,7 +174,7 @@ def test_product_never_imports_the_oracle():
 
 
 def test_native_pass_never_gives_a_workgroup_more_pixels_than_its_int32_accumulators_hold(lib):
-    """the deep-bank pass lets only 512 / B workgroups per image work; its per-wave int32 MFMA accumulators are
+    """the deep-bank pass lets only 768 / B workgroups per image work (round 5: three per CU); its per-wave int32 MFMA accumulators are
     flushed at the end of the pass and hold at most 524 288 pixels of one label per workgroup. The launcher now raises the
     working workgroups so that a workgroup owns at most 262 144 pixels (test hook: gcs_selftest_native_parts)."""
     for b, h, w in [(64, 321, 481), (64, 2048, 2048), (128, 2048, 2048), (32, 4096, 4096), (512, 724, 724), (1, 8192, 8192),
@@ -183,6 +183,6 @@ def test_native_pass_never_gives_a_workgroup_more_pixels_than_its_int32_accumula
         px = -(-h // 8) * -(-w // 8) * 64
         assert eff >= 1 and px / eff <= 262144 + 256, (b, h, w, eff)
         assert eff <= lib.gcs_kmeans_parts_per_image(b, h, w)
-    assert lib.gcs_selftest_native_parts(64, 321, 481) == 8            # the measured configuration is unchanged: 512 workgroups
+    assert lib.gcs_selftest_native_parts(64, 321, 481) == 12           # the measured configuration: 768 workgroups, three per CU
     assert lib.gcs_selftest_native_parts(64, 2048, 2048) == 16         # was 8: 524 288 pixels per workgroup = 2^31 in one accumulator
     assert lib.gcs_selftest_native_parts(0, 8, 8) == 0
