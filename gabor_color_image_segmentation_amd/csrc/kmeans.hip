@@ -763,6 +763,52 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         return;
     }
 
+    // ---- staging: chunk ci (16 bytes at byte 16*ci of the tile) keeps its place inside its level (level 0 swizzled, level-1
+    //      plane rows padded to NV_P1). The FIRST tile's loads go out before the centroid prologue: its HBM latency (3 - 4 us under
+    //      load) and the prologue then overlap (the same move measured 1 % SLOWER in kmeans_pass_mfma_kernel, whose 168 registers
+    //      leave the loads' addresses no room across the prologue: not done there).
+    const int nchunk = lo.tile_bytes >> 4;
+    const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
+              c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
+    // Rounds i < N0 lie wholly inside level 0 (N0 = 6 for the 48-plane level 0 of every bank with 8 orientations, else 0): chunk
+    // tid + 256 i is 16 bytes at offset 16 tid + 4096 i of the tile, plane row (tid >> 5) + 8 i, whose swizzle is that of row tid >> 5
+    // ^ 2 for odd i - ONE address register for all of them, a scalar add on the tile base per round. The other rounds keep a table.
+    v4i st[NV_NST];
+    unsigned sadr[NV_NST - N0];                             // per chunk: LDS byte address << 16 | byte offset inside the tile (both < 65 536)
+    const unsigned s0adr = (unsigned)(size_t)(lds_uchar_ptr)s_mem + (tid >> 5) * NV_P0 + (((tid & 31) ^ nv_swz(tid >> 5)) << 4);
+#pragma unroll
+    for (int i = N0; i < NV_NST; ++i) {
+        const int ci = min(tid + 256 * i, nchunk - 1);
+        int d;
+        if (ci < c1s) d = (ci >> 5) * NV_P0 + ((ci & 31) ^ nv_swz(ci >> 5)) * 16;
+        else if (ci < c2s) d = NV_OFF1 + ((ci - c1s) >> 3) * NV_P1 + ((ci - c1s) & 7) * 16;
+        else if (ci < c3s) d = NV_OFF2 + (ci - c2s) * 16;
+        else d = NV_OFF3 + (ci - c3s) * 16;
+        sadr[i - N0] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
+    }
+    auto stage_load = [&](int tile) {                       // uniform 64-bit tile base + 32-bit lane offset
+        const unsigned char *tb = fb + (size_t)tile * lo.tile_bytes;
+        unsigned o0 = (unsigned)tid * 16u;
+        asm volatile("" : "+v"(o0));                        // (opaque: see below)
+#pragma unroll
+        for (int i = 0; i < N0; ++i) st[i] = kp_load(reinterpret_cast<const v4i *>(tb + i * 4096 + o0), nt_loads);
+#pragma unroll
+        for (int i = N0; i < NV_NST; ++i) {
+            unsigned o = sadr[i - N0] & 0xffffu;            // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
+            asm volatile("" : "+v"(o));                     //  offsets, these spilled - and a reload inside the loop waits for vmcnt(0))
+            st[i] = kp_load(reinterpret_cast<const v4i *>(tb + o), nt_loads);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < N0; ++i) *reinterpret_cast<lds_v4i_ptr>((s0adr ^ ((i & 1) * 32u)) + i * 8 * NV_P0) = st[i];
+#pragma unroll
+        for (int i = N0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sadr[i - N0] >> 16) = st[i];
+    };
+    auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
+    int ltile = g;
+    if (ltile < nlist) stage_load(phys(ltile));
+
     // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
     static_assert(8 * 4 * NV_DL * 2 <= TILE_B, "centroid scratch exceeds the tile buffer");
@@ -825,47 +871,6 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         for (int nt = 0; nt < NV_UT; ++nt) accu[L][nt] = v4i{0, 0, 0, 0};
     int cntacc = 0;
 
-    // ---- staging: chunk ci (16 bytes at byte 16*ci of the tile) keeps its place inside its level; level-0 and level-1
-    //      plane rows get the bank padding of NV_P0 / NV_P1
-    const int nchunk = lo.tile_bytes >> 4;
-    const int c1s = NL > 1 ? lo.off[1] >> 4 : nchunk, c2s = NL > 2 ? lo.off[2] >> 4 : nchunk,
-              c3s = NL > 3 ? lo.off[3] >> 4 : nchunk;
-    // Rounds i < N0 lie wholly inside level 0 (N0 = 6 for the 48-plane level 0 of every bank with 8 orientations, else 0): chunk
-    // tid + 256 i is 16 bytes at offset 16 tid + 4096 i of the tile, plane row (tid >> 5) + 8 i, whose swizzle is that of row tid >> 5
-    // ^ 2 for odd i - ONE address register for all of them, a scalar add on the tile base per round. The other rounds keep a table.
-    v4i st[NV_NST];
-    unsigned sadr[NV_NST - N0];                             // per chunk: LDS byte address << 16 | byte offset inside the tile (both < 65 536)
-    const unsigned s0adr = (unsigned)(size_t)(lds_uchar_ptr)s_mem + (tid >> 5) * NV_P0 + (((tid & 31) ^ nv_swz(tid >> 5)) << 4);
-#pragma unroll
-    for (int i = N0; i < NV_NST; ++i) {
-        const int ci = min(tid + 256 * i, nchunk - 1);
-        int d;
-        if (ci < c1s) d = (ci >> 5) * NV_P0 + ((ci & 31) ^ nv_swz(ci >> 5)) * 16;
-        else if (ci < c2s) d = NV_OFF1 + ((ci - c1s) >> 3) * NV_P1 + ((ci - c1s) & 7) * 16;
-        else if (ci < c3s) d = NV_OFF2 + (ci - c2s) * 16;
-        else d = NV_OFF3 + (ci - c3s) * 16;
-        sadr[i - N0] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
-    }
-    auto stage_load = [&](int tile) {                       // uniform 64-bit tile base + 32-bit lane offset
-        const unsigned char *tb = fb + (size_t)tile * lo.tile_bytes;
-        unsigned o0 = (unsigned)tid * 16u;
-        asm volatile("" : "+v"(o0));                        // (opaque: see below)
-#pragma unroll
-        for (int i = 0; i < N0; ++i) st[i] = kp_load(reinterpret_cast<const v4i *>(tb + i * 4096 + o0), nt_loads);
-#pragma unroll
-        for (int i = N0; i < NV_NST; ++i) {
-            unsigned o = sadr[i - N0] & 0xffffu;            // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
-            asm volatile("" : "+v"(o));                     //  offsets, these spilled - and a reload inside the loop waits for vmcnt(0))
-            st[i] = kp_load(reinterpret_cast<const v4i *>(tb + o), nt_loads);
-        }
-    };
-    auto stage_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < N0; ++i) *reinterpret_cast<lds_v4i_ptr>((s0adr ^ ((i & 1) * 32u)) + i * 8 * NV_P0) = st[i];
-#pragma unroll
-        for (int i = N0; i < NV_NST; ++i) *reinterpret_cast<lds_v4i_ptr>(sadr[i - N0] >> 16) = st[i];
-    };
-
     // update operand coordinates: row um = 2 * cluster + byte, K-group ukg = pixel rows 2 ukg, 2 ukg + 1 of the block
     const int um = lane & 15, ukg = lane >> 4;
     // one-hot bytes (b0 b1 b2 b3) of four pixels -> K-slots (px, t): (b0 0 b1 0 | b2 0 b3 0) for the low-byte rows, shifted up one
@@ -874,9 +879,6 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     // and the cluster's compare pattern comes from the lane number (three invariants fewer than the tile loop can keep).
     const unsigned uselA0 = (um & 1) ? 0x01040004u : 0x04010400u;
 
-    auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
-    int ltile = g;
-    if (ltile < nlist) stage_load(phys(ltile));
     const int s1 = __builtin_amdgcn_readfirstlane(G % ntiles);
     const int q1 = __builtin_amdgcn_readfirstlane(4 * s1 / lo.bx_n), r1 = 4 * s1 - q1 * lo.bx_n;
     const int q2 = __builtin_amdgcn_readfirstlane(4 * (ntiles - s1) / lo.bx_n), r2 = 4 * (ntiles - s1) - q2 * lo.bx_n;
