@@ -28,7 +28,7 @@ def _worker(rank, world, port, per_rank, n_iter, k, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,per_rank", [(2, 2), (2, 1)])
+@pytest.mark.parametrize("world,per_rank", [(2, 2), (2, 1), (8, 1)])      # 8: the target machine's world size
 def test_global_codebook_two_ranks_equals_unsharded_oracle(tmp_path, world, per_rank):
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so
@@ -61,14 +61,14 @@ def _strip_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_gpu):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_row_sharded_image_equals_unsharded_oracle(tmp_path, world):
     """BASELINE config 5 in miniature: one image split into row strips with the halo the bank's kernel needs (6 rows per
     pyramid level = 12 rows: `halo_rows(2, 13)`, the defaults of `shard_rows`; `Segmenter.shard_rows` reads them from its bank)."""
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so
     port = 31500 + (os.getpid() % 2000) + world
-    b, height, width = 2, 60, 40
+    b, height, width = (2, 60, 40) if world < 8 else (1, 112, 40)      # eight strips of 14 rows: each at least the 12-row halo
     mp.spawn(_strip_worker, args=(world, port, b, height, width, 4, 5, str(tmp_path), False), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(world)], axis=1)
     ref = so.segment_batch(synthetic_batch(b, height, width, seed=13), mode="global", k=5, n_iter=4)
@@ -252,7 +252,7 @@ def _owned_rows_worker(rank, world, port, b, height, width, n_iter, k, tmp, use_
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_exchange_between_ranks_equals_unsharded_oracle(tmp_path, world):
     """BASELINE config 5 with the cross-rank halo exchange (SURVEY §8e option (ii)): every rank holds only its own rows;
     the 12 halo rows per interior edge travel rank to rank (point-to-point), nothing comes from a host copy of the whole
@@ -260,7 +260,7 @@ def test_halo_exchange_between_ranks_equals_unsharded_oracle(tmp_path, world):
     from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
     from oracle import spec_oracle as so
     port = 38500 + (os.getpid() % 2000) + world
-    b, height, width = 2, 72, 40
+    b, height, width = (2, 72, 40) if world < 8 else (1, 112, 40)      # eight ranks: 14 own rows each, seven interior edges
     mp.spawn(_owned_rows_worker, args=(world, port, b, height, width, 3, 5, str(tmp_path), False), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)], axis=1)
     ref = so.segment_batch(synthetic_batch(b, height, width, seed=13), mode="global", k=5, n_iter=3)
@@ -280,3 +280,129 @@ def test_halo_exchange_on_gpu_three_ranks(tmp_path, built):
     tapq, shift = so.bank()
     ref = co.segment_batch(synthetic_batch(b, height, width, seed=13), tapq, shift, 6, k=8, n_iter=5, mode="global")
     assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The target's world size: EIGHT ranks. The GPU box admits at most six processes on its card
+# (gpurun's process guard), so eight processes sharing cuda:0 is not something a test may start. Two forms instead:
+#   * eight ranks as eight THREADS of one process (tests/threaded_world.py), every rank through the HIP kernels, the collectives
+#     on device tensors: config 3 (8 x 2 images) and config 5 with host-delivered halos (8 strips of 256 rows of one 2048 x 2048
+#     image);
+#   * eight PROCESSES over gloo for the rank-to-rank halo exchange (point-to-point), five of them on cuda:0 (the pytest process
+#     itself is the sixth on the card) and three computing their strip with the oracle-backed stand-in of tests/fake_ops.py: every rank takes part in every exchange, and exact
+#     integer arithmetic makes the label map independent of who computed which strip.
+# No scaling curve is measured by any of this (one GPU): none is claimed.
+
+@pytest.mark.gpu
+def test_config3_eight_hip_ranks_equal_unsharded_c_oracle(built):
+    """BASELINE config 3 at the target's world size: 8 ranks x 2 images of 136 x 200 (bench.py's sharding), all eight through
+    the HIP kernels on cuda:0, init broadcast + one int64 all-reduce per Lloyd pass on DEVICE tensors == the C oracle's
+    global-codebook result on the unsharded 16-image batch."""
+    from threaded_world import run_threaded
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+    from oracle import c_oracle as co, spec_oracle as so
+    world, per_rank, height, width, n_iter, k = 8, 2, 136, 200, 6, 8
+
+    def rank_fn(rank, world):
+        assert dist.get_world_size() == 8 and dist.get_backend() == "threaded"
+        imgs = synthetic_shard(rank * per_rank, per_rank, height, width, seed=0)
+        seg = Segmenter(k=k, n_iter=n_iter, device="cuda:0")
+        return seg.segment_device(torch.from_numpy(imgs).cuda(), mode="global").cpu().numpy()
+
+    got = np.concatenate(run_threaded(world, rank_fn))
+    tapq, shift = so.bank()
+    ref = co.segment_batch(synthetic_shard(0, world * per_rank, height, width, seed=0), tapq, shift, 6, k=k, n_iter=n_iter,
+                           mode="global")
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_config5_2048_in_eight_strips_of_256_rows_on_gpu(built):
+    """BASELINE config 5 as SURVEY §8e specifies it: ONE 2048 x 2048 image, rank r owns rows [256 r, 256 (r + 1)), 12-row
+    halos delivered with the strip (option (i)); eight ranks through the HIP kernels (threads of one process). The stitched
+    map == the unsharded GPU result == the C oracle's label map of the whole image."""
+    from threaded_world import run_threaded
+    from gabor_color_image_segmentation_amd import Segmenter, shard_rows
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    height = width = 2048
+    imgs = synthetic_batch(1, height, width, seed=41)
+
+    def rank_fn(rank, world):
+        r0, r1, s0, s1 = shard_rows(height, world, rank)
+        assert (r0, r1) == (256 * rank, 256 * (rank + 1)) and s0 == max(0, r0 - 12) and s1 == min(height, r1 + 12)
+        seg = Segmenter(n_iter=4, device="cuda:0")
+        strip = torch.from_numpy(np.ascontiguousarray(imgs[:, s0:s1])).cuda()
+        return seg.segment_rows_sharded_device(strip, r0, r1, s0, height).cpu().numpy().astype(np.uint8)
+
+    got = np.concatenate(run_threaded(8, rank_fn), axis=1)
+    ref = Segmenter(n_iter=4).segment_batch(imgs, mode="global")
+    assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.uint8)) and len(np.unique(ref)) > 1
+    from oracle import c_oracle as co, spec_oracle as so
+    tapq, shift = so.bank()
+    assert np.array_equal(ref, co.segment_batch(imgs, tapq, shift, 6, n_iter=4, mode="global"))
+
+
+def _mixed_owned_rows_worker(rank, world, port, n_gpu_ranks, height, width, n_iter, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gabor_color_image_segmentation_amd import Segmenter, make_bank, shard_rows
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    imgs = synthetic_batch(1, height, width, seed=41)
+    r0, r1, _, _ = shard_rows(height, world, rank)
+    owned = torch.from_numpy(np.ascontiguousarray(imgs[:, r0:r1]))             # this rank never sees a neighbour's rows
+    if rank < n_gpu_ranks:
+        seg = Segmenter(n_iter=n_iter, device="cuda:0")
+        owned = owned.cuda()
+    else:                                                                      # (the card takes six processes - this session's included -, the world is eight)
+        from fake_ops import OracleOps
+        seg = Segmenter(n_iter=n_iter, ops=OracleOps(make_bank()))
+    out = seg.segment_owned_rows_device(owned, height)
+    np.save(os.path.join(tmp, f"mixed_{rank}.npy"), out.cpu().numpy().astype(np.uint8))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config5_halo_exchange_eight_ranks_2048(tmp_path, built):
+    """Option (ii) of SURVEY §8e at the target's world size and config 5's real size: eight PROCESSES each hold only their
+    own 256 rows of one 2048 x 2048 image, the 12 halo rows of the seven interior edges travel rank to rank (gloo here, RCCL
+    send / recv on a multi-GPU node), then init publication + one all-reduce per pass. Five ranks run the HIP kernels on cuda:0
+    (with the session's own process: the card's limit of six), three the oracle-backed stand-in. Stitched map == the unsharded GPU result."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch
+    height = width = 2048
+    port = 40500 + (os.getpid() % 2000)
+    mp.spawn(_mixed_owned_rows_worker, args=(8, port, 5, height, width, 3, str(tmp_path)), nprocs=8, join=True)
+    got = np.concatenate([np.load(tmp_path / f"mixed_{r}.npy") for r in range(8)], axis=1)
+    ref = Segmenter(n_iter=3).segment_batch(synthetic_batch(1, height, width, seed=41), mode="global")
+    assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.uint8)) and len(np.unique(ref)) > 1
+
+
+def test_eight_threaded_ranks_on_cpu_equal_unsharded_oracle():
+    """The thread-backed world itself, on CPU with the oracle-backed stand-in: 8 ranks, batch sharding and row sharding
+    (host-delivered halos) == the unsharded oracle. Keeps tests/threaded_world.py honest where no GPU is present."""
+    sys.path.insert(0, HERE)
+    from threaded_world import run_threaded
+    from fake_ops import OracleOps
+    from gabor_color_image_segmentation_amd import Segmenter, make_bank, shard_rows
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_batch, synthetic_shard
+    from oracle import spec_oracle as so
+
+    def batch_fn(rank, world):
+        seg = Segmenter(k=6, n_iter=4, ops=OracleOps(make_bank()))
+        return seg.segment_device(torch.from_numpy(synthetic_shard(rank, 1, 24, 40, seed=5)), mode="global").numpy()
+
+    got = np.concatenate(run_threaded(8, batch_fn))
+    assert np.array_equal(got, so.segment_batch(synthetic_batch(8, 24, 40, seed=5), mode="global", k=6, n_iter=4))
+    imgs = synthetic_batch(1, 112, 40, seed=13)
+
+    def rows_fn(rank, world):
+        r0, r1, s0, s1 = shard_rows(112, world, rank)
+        seg = Segmenter(k=5, n_iter=4, ops=OracleOps(make_bank()))
+        return seg.segment_rows_sharded_device(torch.from_numpy(np.ascontiguousarray(imgs[:, s0:s1])), r0, r1, s0, 112).numpy()
+
+    got = np.concatenate(run_threaded(8, rows_fn), axis=1)
+    assert np.array_equal(got, so.segment_batch(imgs, mode="global", k=5, n_iter=4))
