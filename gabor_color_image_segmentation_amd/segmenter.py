@@ -60,6 +60,75 @@ _ENV_DEBUG = DebugSwitches(os.environ.get("GCS_DEBUG", ""))
 
 
 
+class _CaptureGuard:
+    """Process-wide order for HIP graph captures of this module.
+
+    A torch ``CUDAGraph`` destroyed while a stream capture is open throws out of its destructor and ``std::terminate`` ends the
+    process (profiles/r4_notes.md). Three rules keep that from happening through this module, whatever threads use it:
+
+    * captures are SERIALISED: one lock is held from the garbage collection in front of a capture to its end, so the cyclic
+      collector - a process-global switch - is turned off by the one capturer there is and turned back on (if it was on) when
+      that capture has ended, never inside another thread's open capture;
+    * graph entries are never dropped where a capture might be open: evicted entries and the entries of a Segmenter that is
+      being finalised go through ``retire``, which frees them at once when no capture is open and parks them otherwise
+      (drained at the end of the capture, under the lock);
+    * a capture that fails is not silent: ``fell_back`` warns once per plan key."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()      # not re-entrant: a plan finalised BY the capturing thread must park its graphs too
+        self._parked = []            # retired graph entries waiting for the open capture to end
+        self._warned = set()
+
+    def capture(self, torch, graph, body):
+        """Capture ``body()`` into ``graph`` (thread_local error mode: only this thread is restricted while it captures).
+        Returns True, or False when the capture was refused (the caller then launches eagerly)."""
+        import gc
+        with self._lock:
+            gc.collect()             # dead cycles that hold graphs: finalise them NOW, not between capture_begin and capture_end
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    body()
+                return True
+            except RuntimeError:
+                return False
+            finally:
+                if was_enabled:
+                    gc.enable()
+                self._drain()
+
+    def retire(self, entries):
+        """Drop graph entries (dicts holding a CUDAGraph and its buffers): now if no capture is open, else after it."""
+        entries = [e for e in entries if e is not None]
+        if not entries:
+            return
+        if self._lock.acquire(blocking=False):
+            try:
+                self._drain()
+                del entries[:]       # (the last references, unless the caller keeps some: freed here, outside any capture)
+            finally:
+                self._lock.release()
+        else:
+            self._parked.extend(entries)      # list.extend is atomic under the GIL; drained by the capturer
+
+    def _drain(self):
+        while self._parked:
+            self._parked.pop()
+
+    def fell_back(self, key, err):
+        if key not in self._warned:
+            self._warned.add(key)
+            import warnings
+            warnings.warn(f"gabor_color_image_segmentation_amd: HIP graph capture refused for plan {key} ({err}); this shape runs "
+                          "as eager kernel launches for the life of the plan (slower one-image calls, same results)",
+                          RuntimeWarning, stacklevel=3)
+
+
+_CAPTURES = _CaptureGuard()
+
+
 def _torch():
     import torch
     return torch
@@ -354,6 +423,16 @@ class Segmenter:
         self._copy_pair = None
         self._stagers = None
         self._graphs = {}
+
+    def __del__(self):
+        # a plan dropped in one thread while another thread captures: its graphs leave through the guard (parked until that
+        # capture has ended) instead of being destroyed wherever the last reference happened to die
+        try:
+            ents = list(self._graphs.values())
+            self._graphs.clear()
+            _CAPTURES.retire(ents)
+        except Exception:            # interpreter shutdown: module globals may be gone
+            pass
 
     @property
     def native(self):
@@ -724,29 +803,16 @@ class Segmenter:
                 step()                                     # eager once: first-use work (side-stream creation) outside the capture
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
-                # A torch CUDAGraph that is DESTROYED while a capture is open throws out of its destructor ("operation not
-                # permitted when stream is capturing") and std::terminate ends the process - and this torch no longer
-                # collects garbage before a capture (torch.compiler.config.force_cudagraph_gc is off). Dead reference cycles
-                # that hold a graph (the caller's, another library's; round 4: dead plans of this module, see
-                # profiles/r4_notes.md) must not be finalised between capture_begin and capture_end: collect them now and
-                # keep the cyclic collector off meanwhile. thread_local: only this thread is restricted while it captures
-                # (the default mode fails the allocations and frees of every other thread, and lets theirs fail this capture).
-                import gc
-                gc.collect()
-                gc_was_enabled = gc.isenabled()
-                gc.disable()
-                try:
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        step()
-                except RuntimeError:                       # capture refused (e.g. another capture is open): launch eagerly
+                # capture under the module's guard (_CaptureGuard: serialised, collector off for exactly that long, retired
+                # graphs parked meanwhile); a refused capture (e.g. the caller's own capture is open on this thread) is reported
+                # once and the shape then runs as eager launches
+                if not _CAPTURES.capture(torch, graph, step):
+                    _CAPTURES.fell_back(key, "torch.cuda.graph raised RuntimeError")
                     graph = None
                     torch.cuda.synchronize(dev)
-                finally:
-                    if gc_was_enabled:
-                        gc.enable()
                 ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in, scratch=scratch)
-                if len(self._graphs) >= 4:
-                    self._graphs.pop(next(iter(self._graphs)))
+                if len(self._graphs) >= 4:                 # evicted plans leave through the guard: never inside an open capture
+                    _CAPTURES.retire([self._graphs.pop(next(iter(self._graphs)))])
                 self._graphs[key] = ent
             cur = torch.cuda.current_stream(dev)
             _stage(ent["pin_in"], imgs)

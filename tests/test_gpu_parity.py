@@ -237,6 +237,91 @@ def test_capturing_a_plan_survives_dead_graph_cycles(torch_cuda):
     assert np.array_equal(seg.segment_batch(img), got)         # replay
 
 
+def test_two_threads_capture_their_first_plans_at_the_same_time(torch_cuda):
+    """the collect / gc.disable() / capture / gc.enable() sequence is process-global state. Two Segmenters
+    whose FIRST one-image calls (eager step + capture) overlap on two threads, with dead graph cycles lying around, the
+    collector set to run at every allocation, and plans being dropped meanwhile: captures are serialised by the module's guard,
+    the collector comes back on only after the capture that turned it off, retired graphs wait for the open capture to end.
+    Results == the oracle, the collector is enabled afterwards, nothing aborts."""
+    import gc
+    import threading
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd import segmenter as sg
+
+    def dead_cycle_with_a_graph():
+        g = torch.cuda.CUDAGraph()
+        x = torch.zeros(64, device="cuda")
+        with torch.cuda.graph(g):
+            x += 1
+        holder = {"graph": g, "x": x}
+        holder["self"] = holder
+
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(4):
+            dead_cycle_with_a_graph()
+    finally:
+        gc.enable()
+    imgs = {0: _synth(1, 56, 88, seed=81), 1: _synth(1, 64, 72, seed=82)}
+    want = {i: so.segment(imgs[i][0], n_iter=2) for i in imgs}
+    start = threading.Barrier(2)
+    got, errs = {}, []
+
+    def run(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                start.wait()
+                for rep in range(3):                            # every round: a fresh plan (eager step + capture), then a replay
+                    seg = Segmenter(n_iter=2)
+                    a = seg.segment_batch(imgs[i])
+                    b = seg.segment_batch(imgs[i])
+                    assert np.array_equal(a, b)
+                    got[i] = a
+                    del seg                                     # dropped while the other thread may be capturing
+        except BaseException as e:  # noqa: B036
+            errs.append((i, repr(e)))
+
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        threads = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+    finally:
+        gc.set_threshold(*old)
+    assert not errs, errs
+    assert gc.isenabled()                                       # re-enabled by the capturer that disabled it, and only then
+    assert not sg._CAPTURES._parked or sg._CAPTURES.retire([]) is None
+    for i in imgs:
+        assert np.array_equal(got[i][0], want[i])
+
+
+def test_a_refused_capture_warns_once_and_runs_eagerly(torch_cuda):
+    """A capture that cannot be taken (here: the caller's own capture is open on this thread) used to degrade the shape to eager
+    launches silently; now it says so, once per plan key, and the result is the same."""
+    import warnings
+    import torch
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd import segmenter as sg
+    seg = Segmenter(n_iter=2)
+    img = _synth(1, 48, 80, seed=83)
+    real = sg._CAPTURES.capture
+    sg._CAPTURES.capture = lambda torch_, graph, body: False    # what a RuntimeError out of torch.cuda.graph turns into
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = seg.segment_batch(img)
+            again = seg.segment_batch(img)
+    finally:
+        sg._CAPTURES.capture = real
+    assert sum("graph capture refused" in str(x.message) for x in w) == 1
+    assert np.array_equal(got[0], so.segment(img[0], n_iter=2)) and np.array_equal(got, again)
+
+
 def test_segment_stream_equals_segment_batch(torch_cuda):
     """The pipelined host API (three streams, depth + 1 buffer slots): seven batches through segment_stream give, in order,
     exactly what segment_batch gives for each - both label dtypes, both codebook modes, a depth larger than the input."""
