@@ -38,7 +38,8 @@ def val_split():
     for shape in sorted({pack["img_" + i].shape[:2] for i in ids}):
         group = [i for i in ids if pack["img_" + i].shape[:2] == shape]
         labels = seg.segment_device(torch.from_numpy(np.stack([pack["img_" + i] for i in group])).cuda())
-        for i, s in zip(group, all_scores_batch_device(labels, *truth.stack(group))):
+        # ground truth resident on the device in the scorer's form (prepared once per shape group; a data-set loop keeps it)
+        for i, s in zip(group, all_scores_batch_device(labels, truth.to_device(group), n_segments=seg.k)):
             rows[i] = s
             print("%-8s Regions: %d Recall: %.4f Precision: %.4f F-measure: %.4f   (reference class: %.4f)"
                   % (i, s["regions"], s["recall"], s["precision"], s["fmeasure"], ref[i]["v2"]["fmeasure"]))

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -49,6 +49,13 @@ SIGNATURES = {
     "gcs_boundary_batch_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "gcs_boundary_counts_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gcs_region_counts_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gcs_region_counts_batch_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gcs_region_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "gcs_score_batch_resident": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp]),
+    "gcs_bit_planes_bytes": (_sz, [_i, _i, _i]),
+    "gcs_truth_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gcs_boundary_counts_resident": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gcs_connected_scratch_bytes": (_sz, [_i, _i, _i]),
     "gcs_connected_regions": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
 }

@@ -154,6 +154,211 @@ extern "C" int gcs_boundary_counts_batch(const int32_t *labels, const uint16_t *
     return boundary_counts_launch(labels, truth, img_of, B, T, H, W, scratch, counts, stream, "gcs_boundary_counts_batch");
 }
 
+// ============================================================ boundary scoring on resident ground truth (round 5)
+// The annotator maps are constants of the data set (/root/reference/BSD_metrics/metrics.py:48-49 recomputes
+// find_boundaries(truth) for every image it scores, groundtruth.py:44-48 rescans the directories per id): their thick boundaries
+// bd(T_t), the 5x5 dilation dil5(bd(T_t)) and sum bd(T_t) are computed ONCE per annotator map (gcs_truth_prepare) and kept on the
+// device as BIT planes, rows of 64-bit words (bit i of word w of a row = pixel 64 w + i), all bd planes first, then all dil5
+// planes. A scoring call derives the two bit planes of each label map and the three sums are AND + popcount over 2 568 words per
+// plane (321 x 481): kilobytes, where round 4 uploaded 40 MB of annotator maps per 24 images and re-derived 129 byte planes.
+__host__ __device__ static inline int bits_wp(int W) { return (W + 63) / 64; }
+
+// bd bit planes of M maps: one wave per 64 consecutive pixels of a row (coalesced), the plane word by ballot. `smax`: per-map
+// maximum value (metrics.py:51 for the label maps; zeroed by the caller), or NULL.
+template <typename T>
+__global__ __launch_bounds__(256) void bits_boundary_kernel(const T *__restrict__ maps, int M, int H, int W,
+                                                            unsigned long long *__restrict__ bd, int *__restrict__ smax) {
+    const int wp = bits_wp(W);
+    const long long nw = (long long)M * H * wp;
+    const int lane = threadIdx.x & 63;
+    for (long long wi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wi < nw; wi += (long long)gridDim.x * 4) {
+        const int wx = (int)(wi % wp), y = (int)((wi / wp) % H), m = (int)(wi / ((long long)wp * H));
+        const int x = wx * 64 + lane;
+        const T *mp = maps + (size_t)m * H * W;
+        bool b = false;
+        int v = 0;
+        if (x < W) {
+            b = thick_boundary(mp, H, W, y, x);
+            v = (int)mp[(size_t)y * W + x];
+        }
+        const unsigned long long word = __ballot(b);
+        if (lane == 0) bd[wi] = word;
+        if (smax) {
+            // one atomic per wave only while it can still raise the maximum: unconditional, 41 000 waves hammered 16 addresses and
+            // this kernel took 305 us for 16 BSD label maps (6 us without)
+            for (int s = 32; s >= 1; s >>= 1) v = max(v, __shfl_xor(v, s));
+            if (lane == 0 && v > __hip_atomic_load(&smax[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&smax[m], v);
+        }
+    }
+}
+
+// dil5 bit planes: OR over the 5 x 5 neighbourhood; pixels outside the image count as 0 (dilation(., rectangle(5,5)) through
+// scipy's max filter with its reflect border sees in-image values only)
+__global__ __launch_bounds__(256) void bits_dilate_kernel(const unsigned long long *__restrict__ bd, int M, int H, int W,
+                                                          unsigned long long *__restrict__ dil) {
+    const int wp = bits_wp(W);
+    const long long nw = (long long)M * H * wp;
+    const unsigned long long last_mask = (W & 63) ? ((1ull << (W & 63)) - 1) : ~0ull;
+    for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < nw; wi += (long long)gridDim.x * blockDim.x) {
+        const int wx = (int)(wi % wp), y = (int)((wi / wp) % H);
+        const unsigned long long *row0 = bd + (wi - wx) - (long long)y * wp;    // row 0 of this map
+        unsigned long long acc = 0;
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            const unsigned long long *r = row0 + (long long)yy * wp;
+            const unsigned long long w = r[wx], pv = wx > 0 ? r[wx - 1] : 0ull, nx = wx + 1 < wp ? r[wx + 1] : 0ull;
+            acc |= w | (w << 1) | (w << 2) | (w >> 1) | (w >> 2) | (pv >> 63) | (pv >> 62) | (nx << 63) | (nx << 62);
+        }
+        dil[wi] = wx == wp - 1 ? acc & last_mask : acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bits_popcount_kernel(const unsigned long long *__restrict__ planes, int words,
+                                                            unsigned long long *__restrict__ out) {
+    __shared__ unsigned s_sum[4];
+    const unsigned long long *p = planes + (size_t)blockIdx.x * words;
+    unsigned c = 0;
+    for (int i = threadIdx.x; i < words; i += 256) c += __popcll(p[i]);
+    for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (unsigned long long)s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// 5 x 5 dilation of one word of a bd plane (rows of `wp` words, H rows), see bits_dilate_kernel
+__device__ __forceinline__ unsigned long long bits_dilate_word(const unsigned long long *__restrict__ plane, int H, int wp, int y,
+                                                               int wx, unsigned long long last_mask) {
+    unsigned long long acc = 0;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const unsigned long long *r = plane + (long long)yy * wp;
+        const unsigned long long w = r[wx], pv = wx > 0 ? r[wx - 1] : 0ull, nx = wx + 1 < wp ? r[wx + 1] : 0ull;
+        acc |= w | (w << 1) | (w << 2) | (w >> 1) | (w >> 2) | (pv >> 63) | (pv >> 62) | (nx << 63) | (nx << 62);
+    }
+    return wx == wp - 1 ? acc & last_mask : acc;
+}
+
+// One workgroup per output plane q (no atomics, no zeroing): q < B: counts[q] = sum bd(L_q); else annotator t = q - B of image
+// b = img_of[t]: counts[B + 3t] = sum dil5(bd(L_b)) & bd(T_t), [B + 3t + 1] = sum bd(T_t) (prepared), [B + 3t + 2] = sum bd(L_b) &
+// dil5(bd(T_t)). Annotator planes [2][T][words] (bd, then dil5). Label planes: [2][B][words], or (INLINE) the bd planes alone,
+// dilated word by word right here (a label plane is dilated once per annotator of its image, 15 loads instead of one from a few
+// KB that sit in L2: cheaper than the launch it saves).
+template <bool INLINE>   // INLINE: dilate the label planes word by word here (one launch less; measured 28 us against 5 + 8: not used)
+__global__ __launch_bounds__(256) void bits_counts_kernel(const unsigned long long *__restrict__ lab,
+                                                          const unsigned long long *__restrict__ tru,
+                                                          const unsigned long long *__restrict__ tru_bd_counts,
+                                                          const int32_t *__restrict__ img_of, int B, int T, int H, int W,
+                                                          unsigned long long *__restrict__ counts) {
+    __shared__ unsigned s_sum[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int wp = bits_wp(W), words = H * wp;
+    const unsigned long long last_mask = (W & 63) ? ((1ull << (W & 63)) - 1) : ~0ull;
+    unsigned c0 = 0, c1 = 0;
+    if (q < B) {
+        const unsigned long long *l = lab + (size_t)q * words;
+        for (int i = tid; i < words; i += 256) c0 += __popcll(l[i]);
+    } else {
+        const int t = q - B, b = img_of[t];
+        const unsigned long long *lbd = lab + (size_t)b * words, *ldil = lab + ((size_t)B + b) * words;
+        const unsigned long long *tbd = tru + (size_t)t * words, *tdil = tru + ((size_t)T + t) * words;
+        for (int i = tid; i < words; i += 256) {
+            const unsigned long long ld = INLINE ? bits_dilate_word(lbd, H, wp, i / wp, i % wp, last_mask) : ldil[i];
+            c0 += __popcll(ld & tbd[i]);
+            c1 += __popcll(lbd[i] & tdil[i]);
+        }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        c0 += __shfl_xor(c0, s);
+        c1 += __shfl_xor(c1, s);
+    }
+    if ((tid & 63) == 0) {
+        s_sum[0][tid >> 6] = c0;
+        s_sum[1][tid >> 6] = c1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long r0 = (unsigned long long)s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+        const unsigned long long r1 = (unsigned long long)s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+        if (q < B) counts[q] = r0;
+        else {
+            counts[B + 3 * (q - B)] = r0;
+            counts[B + 3 * (q - B) + 1] = tru_bd_counts[q - B];
+            counts[B + 3 * (q - B) + 2] = r1;
+        }
+    }
+}
+
+// several small buffers zeroed in ONE launch (a hipMemsetAsync each is a launch each)
+struct ZeroList { unsigned *p[4]; unsigned n[4]; };
+__global__ void zero_kernel(ZeroList z) {
+    for (int k = 0; k < 4; ++k)
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n[k]; i += gridDim.x * blockDim.x) z.p[k][i] = 0u;
+}
+
+__global__ void narrow_u16_u8_kernel(const uint16_t *__restrict__ in, size_t n, uint8_t *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (uint8_t)in[i];
+}
+
+static inline unsigned grid_for(long long items, int per_block, unsigned cap) {
+    const long long g = (items + per_block - 1) / per_block;
+    return (unsigned)(g < 1 ? 1 : g > cap ? cap : g);
+}
+
+extern "C" size_t gcs_bit_planes_bytes(int M, int H, int W) {
+    if (M <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)M * 2 * H * bits_wp(W) * sizeof(unsigned long long);
+}
+
+extern "C" int gcs_truth_prepare(const uint16_t *truth, int T, int H, int W, void *planes, uint64_t *bd_counts, uint8_t *truth8,
+                                 gcs_stream_t stream) {
+    if (!truth || !planes || !bd_counts) return gcs_fail(GCS_EINVAL, "gcs_truth_prepare: NULL pointer");
+    if (T <= 0 || T > 1000000 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_truth_prepare: bad shape");
+    const int words = H * bits_wp(W);
+    const long long nw = (long long)T * words;
+    unsigned long long *bd = static_cast<unsigned long long *>(planes), *dil = bd + nw;
+    hipLaunchKernelGGL(bits_boundary_kernel<uint16_t>, dim3(grid_for(nw, 4, 16384)), dim3(256), 0, stream, truth, T, H, W, bd,
+                       (int *)nullptr);
+    GCS_CHECK_LAUNCH("gcs_truth_prepare(boundaries)");
+    hipLaunchKernelGGL(bits_dilate_kernel, dim3(grid_for(nw, 256, 16384)), dim3(256), 0, stream, bd, T, H, W, dil);
+    GCS_CHECK_LAUNCH("gcs_truth_prepare(dilation)");
+    hipLaunchKernelGGL(bits_popcount_kernel, dim3(T), dim3(256), 0, stream, bd, words, reinterpret_cast<unsigned long long *>(bd_counts));
+    GCS_CHECK_LAUNCH("gcs_truth_prepare(counts)");
+    if (truth8) {
+        const size_t n = (size_t)T * H * W;
+        hipLaunchKernelGGL(narrow_u16_u8_kernel, dim3(grid_for((long long)n, 256, 8192)), dim3(256), 0, stream, truth, n, truth8);
+        GCS_CHECK_LAUNCH("gcs_truth_prepare(narrow)");
+    }
+    return GCS_OK;
+}
+
+extern "C" int gcs_boundary_counts_resident(const int32_t *labels, const void *truth_planes, const uint64_t *truth_bd_counts,
+                                            const int32_t *img_of, int B, int T, int H, int W, void *scratch, uint64_t *counts,
+                                            int32_t *seg_max, gcs_stream_t stream) {
+    if (!labels || !truth_planes || !truth_bd_counts || !img_of || !scratch || !counts)
+        return gcs_fail(GCS_EINVAL, "gcs_boundary_counts_resident: NULL pointer");
+    if (B <= 0 || T <= 0 || B + T > 1000000 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_boundary_counts_resident: bad shape");
+    const int words = H * bits_wp(W);
+    const long long nw = (long long)B * words;
+    unsigned long long *bd = static_cast<unsigned long long *>(scratch), *dil = bd + nw;
+    if (seg_max) {
+        hipError_t e = hipMemsetAsync(seg_max, 0, (size_t)B * sizeof(int32_t), stream);
+        if (e != hipSuccess) return gcs_hip_fail(e, "gcs_boundary_counts_resident(memset)");
+    }
+    hipLaunchKernelGGL(bits_boundary_kernel<int32_t>, dim3(grid_for(nw, 4, 16384)), dim3(256), 0, stream, labels, B, H, W, bd, seg_max);
+    GCS_CHECK_LAUNCH("gcs_boundary_counts_resident(boundaries)");
+    hipLaunchKernelGGL(bits_dilate_kernel, dim3(grid_for(nw, 256, 16384)), dim3(256), 0, stream, bd, B, H, W, dil);
+    GCS_CHECK_LAUNCH("gcs_boundary_counts_resident(dilation)");
+    hipLaunchKernelGGL(bits_counts_kernel<false>, dim3(B + T), dim3(256), 0, stream, bd, static_cast<const unsigned long long *>(truth_planes),
+                       reinterpret_cast<const unsigned long long *>(truth_bd_counts), img_of, B, T, H, W,
+                       reinterpret_cast<unsigned long long *>(counts));
+    GCS_CHECK_LAUNCH("gcs_boundary_counts_resident");
+    return GCS_OK;
+}
+
 // ================================================================== connected regions (§8f-4)
 // SPEC.md §7: 4-connected components of equal labels, renumbered 0,1,2,... in raster order of each
 // component's first pixel (so "Regions" = max+1 at /root/reference/BSD_metrics/metrics.py:51 counts
@@ -268,8 +473,9 @@ extern "C" int gcs_connected_regions(const int32_t *labels, int B, int H, int W,
 // atomic on a handful of addresses), global atomics otherwise (connected regions: thousands of sparse rows).
 // Batched: blockIdx.y = image b with annotators first[b] .. first[b+1]-1 of the concatenated truth stack (first == NULL:
 // one image with annotators 0 .. A-1); hist [T][n_seg][stride], area / perim [B][n_seg].
+template <typename TT>
 __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__restrict__ labels,
-                                                            const uint16_t *__restrict__ truth,
+                                                            const TT *__restrict__ truth,
                                                             const int32_t *__restrict__ first, int A, int H, int W,
                                                             int n_seg, int stride, int use_lds,
                                                             unsigned *__restrict__ hist, unsigned *__restrict__ area,
@@ -315,20 +521,23 @@ __global__ __launch_bounds__(256) void region_counts_kernel(const int32_t *__res
     }
 }
 
-static int region_counts_launch(const int32_t *labels, const uint16_t *truth, const int32_t *first, int B, int T, int Amax,
+template <typename TT>
+static int region_counts_launch(const int32_t *labels, const TT *truth, const int32_t *first, int B, int T, int Amax,
                                 int H, int W, int n_segments, int n_truth_labels, uint32_t *hist, uint32_t *area,
-                                uint32_t *perim, hipStream_t stream, const char *who) {
+                                uint32_t *perim, hipStream_t stream, const char *who, bool zeroed = false) {
     const size_t n_hist = (size_t)T * n_segments * n_truth_labels;
-    hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return gcs_hip_fail(e, who);
+    if (!zeroed) {
+        hipError_t e = hipMemsetAsync(hist, 0, n_hist * sizeof(uint32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(area, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(perim, 0, (size_t)B * n_segments * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return gcs_hip_fail(e, who);
+    }
     const size_t lds = ((size_t)Amax * n_segments * n_truth_labels + 2 * (size_t)n_segments) * sizeof(unsigned);
     const int use_lds = lds <= 48 * 1024;
     const int P = H * W;
     int blocks = use_lds ? min(256, (P + 1023) / 1024) : min(2048, (P + 255) / 256);
     if (B > 16) blocks = min(blocks, 32);
-    hipLaunchKernelGGL(region_counts_kernel, dim3(blocks, B), dim3(256), use_lds ? lds : 0, stream, labels, truth, first,
+    hipLaunchKernelGGL(region_counts_kernel<TT>, dim3(blocks, B), dim3(256), use_lds ? lds : 0, stream, labels, truth, first,
                        Amax, H, W, n_segments, n_truth_labels, use_lds, hist, area, perim);
     GCS_CHECK_LAUNCH(who);
     return GCS_OK;
@@ -355,4 +564,116 @@ extern "C" int gcs_region_counts_batch(const int32_t *labels, const uint16_t *tr
         return gcs_fail(GCS_EINVAL, "gcs_region_counts_batch: bad shape");
     return region_counts_launch(labels, truth, first, B, T, max_annotators, H, W, n_segments, n_truth_labels, hist, area,
                                 perim, stream, "gcs_region_counts_batch");
+}
+
+// The two integer sums metrics.py:128-140 takes from an annotator's contingency table, one workgroup per annotator map t of image
+// b = img_of[t]:  under[t] = sum_seg (area[b][seg] - max_col hist[t][seg][col])                       (metrics.py:129-130)
+//                 under_np[t] = sum_seg sum_col min(hist[t][seg][col], rowsum[t][seg] - hist[t][seg][col])   (metrics.py:137-139)
+// Integers: exact in any order. The host then needs 16 bytes per annotator instead of the table (109 x 8 x 114 counters for 16 BSD
+// images) and its array passes over it.
+__global__ __launch_bounds__(256) void region_reduce_kernel(const unsigned *__restrict__ hist, const unsigned *__restrict__ area,
+                                                            const int32_t *__restrict__ img_of, int n_seg, int stride,
+                                                            unsigned long long *__restrict__ under,
+                                                            unsigned long long *__restrict__ under_np) {
+    __shared__ unsigned long long s_u[4], s_n[4];
+    const int t = blockIdx.x, b = img_of[t], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned *h = hist + (size_t)t * n_seg * stride;
+    unsigned long long u = 0, n = 0;                        // (lane 0 of each wave carries the wave's share)
+    for (int seg = wave; seg < n_seg; seg += 4) {           // one wave per table row, lanes across its columns
+        const unsigned *row = h + (size_t)seg * stride;
+        unsigned mx = 0;
+        unsigned long long sum = 0;
+        for (int c = lane; c < stride; c += 64) {
+            const unsigned v = row[c];
+            mx = v > mx ? v : mx;
+            sum += v;
+        }
+        for (int s = 32; s >= 1; s >>= 1) {
+            mx = max(mx, (unsigned)__shfl_xor((int)mx, s));
+            sum += __shfl_xor(sum, s);
+        }
+        unsigned long long mn = 0;
+        for (int c = lane; c < stride; c += 64) {
+            const unsigned long long v = row[c], o = sum - v;
+            mn += v < o ? v : o;
+        }
+        for (int s = 32; s >= 1; s >>= 1) mn += __shfl_xor(mn, s);
+        u += (unsigned long long)area[(size_t)b * n_seg + seg] - mx;    // area >= row sum >= max: never negative
+        n += mn;
+    }
+    if (lane == 0) {
+        s_u[wave] = u;
+        s_n[wave] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        under[t] = s_u[0] + s_u[1] + s_u[2] + s_u[3];
+        under_np[t] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    }
+}
+
+extern "C" int gcs_region_reduce(const uint32_t *hist, const uint32_t *area, const int32_t *img_of, int T, int n_segments,
+                                 int n_truth_labels, uint64_t *under, uint64_t *under_np, gcs_stream_t stream) {
+    if (!hist || !area || !img_of || !under || !under_np) return gcs_fail(GCS_EINVAL, "gcs_region_reduce: NULL pointer");
+    if (T <= 0 || T > 1000000 || n_segments <= 0 || n_truth_labels <= 0) return gcs_fail(GCS_EINVAL, "gcs_region_reduce: bad shape");
+    hipLaunchKernelGGL(region_reduce_kernel, dim3(T), dim3(256), 0, stream, hist, area, img_of, n_segments, n_truth_labels,
+                       reinterpret_cast<unsigned long long *>(under), reinterpret_cast<unsigned long long *>(under_np));
+    GCS_CHECK_LAUNCH("gcs_region_reduce");
+    return GCS_OK;
+}
+
+// the same tables from annotator maps narrowed to uint8 (gcs_truth_prepare: BSD500's largest annotator label is 208), half the bytes
+extern "C" int gcs_region_counts_batch_u8(const int32_t *labels, const uint8_t *truth8, const int32_t *first, int B, int T,
+                                          int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist,
+                                          uint32_t *area, uint32_t *perim, gcs_stream_t stream) {
+    if (!labels || !truth8 || !first || !hist || !area || !perim)
+        return gcs_fail(GCS_EINVAL, "gcs_region_counts_batch_u8: NULL pointer");
+    if (B <= 0 || B > 65535 || T <= 0 || max_annotators <= 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL ||
+        n_segments <= 0 || n_truth_labels <= 0 || n_truth_labels > 256 || (long long)T * n_segments * n_truth_labels > 0x3fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_region_counts_batch_u8: bad shape");
+    return region_counts_launch(labels, truth8, first, B, T, max_annotators, H, W, n_segments, n_truth_labels, hist, area,
+                                perim, stream, "gcs_region_counts_batch_u8");
+}
+
+// Everything evaluate.metrics.get_metrics() needs of a batch, on resident ground truth, in SIX launches: zero | bd(L) bit planes +
+// label maxima | their dilation | boundary counts | region tables | their reduction.
+extern "C" int gcs_score_batch_resident(const int32_t *labels, const void *truth_planes, const uint64_t *truth_bd_counts,
+                                        const void *truth_maps, int truth_is_u8, const int32_t *first, const int32_t *img_of, int B,
+                                        int T, int max_annotators, int H, int W, int n_segments, int n_truth_labels, void *scratch,
+                                        uint32_t *hist, uint64_t *counts, int32_t *seg_max, uint32_t *area, uint32_t *perim,
+                                        uint64_t *under, uint64_t *under_np, gcs_stream_t stream) {
+    if (!labels || !truth_planes || !truth_bd_counts || !truth_maps || !first || !img_of || !scratch || !hist || !counts || !seg_max ||
+        !area || !perim || !under || !under_np)
+        return gcs_fail(GCS_EINVAL, "gcs_score_batch_resident: NULL pointer");
+    if (B <= 0 || B > 65535 || T <= 0 || B + T > 1000000 || max_annotators <= 0 || H <= 0 || W <= 0 ||
+        (long long)H * W > 0x7fffffffLL || n_segments <= 0 || n_truth_labels <= 0 || (truth_is_u8 && n_truth_labels > 256) ||
+        (long long)T * n_segments * n_truth_labels > 0x3fffffffLL)
+        return gcs_fail(GCS_EINVAL, "gcs_score_batch_resident: bad shape");
+    const int words = H * bits_wp(W);
+    const long long nw = (long long)B * words;
+    ZeroList z;
+    z.p[0] = hist; z.n[0] = (unsigned)((size_t)T * n_segments * n_truth_labels);
+    z.p[1] = area; z.n[1] = (unsigned)(B * n_segments);
+    z.p[2] = perim; z.n[2] = (unsigned)(B * n_segments);
+    z.p[3] = reinterpret_cast<unsigned *>(seg_max); z.n[3] = (unsigned)B;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for((long long)z.n[0], 256, 1024)), dim3(256), 0, stream, z);
+    GCS_CHECK_LAUNCH("gcs_score_batch_resident(zero)");
+    unsigned long long *bd = static_cast<unsigned long long *>(scratch);
+    hipLaunchKernelGGL(bits_boundary_kernel<int32_t>, dim3(grid_for(nw, 4, 16384)), dim3(256), 0, stream, labels, B, H, W, bd, seg_max);
+    GCS_CHECK_LAUNCH("gcs_score_batch_resident(boundaries)");
+    hipLaunchKernelGGL(bits_dilate_kernel, dim3(grid_for(nw, 256, 16384)), dim3(256), 0, stream, bd, B, H, W, bd + nw);
+    GCS_CHECK_LAUNCH("gcs_score_batch_resident(dilation)");
+    hipLaunchKernelGGL(bits_counts_kernel<false>, dim3(B + T), dim3(256), 0, stream, bd, static_cast<const unsigned long long *>(truth_planes),
+                       reinterpret_cast<const unsigned long long *>(truth_bd_counts), img_of, B, T, H, W,
+                       reinterpret_cast<unsigned long long *>(counts));
+    GCS_CHECK_LAUNCH("gcs_score_batch_resident(counts)");
+    int rc = truth_is_u8 ? region_counts_launch(labels, static_cast<const uint8_t *>(truth_maps), first, B, T, max_annotators, H, W,
+                                                n_segments, n_truth_labels, hist, area, perim, stream, "gcs_score_batch_resident(regions)", true)
+                         : region_counts_launch(labels, static_cast<const uint16_t *>(truth_maps), first, B, T, max_annotators, H, W,
+                                                n_segments, n_truth_labels, hist, area, perim, stream, "gcs_score_batch_resident(regions)", true);
+    if (rc != GCS_OK) return rc;
+    hipLaunchKernelGGL(region_reduce_kernel, dim3(T), dim3(256), 0, stream, hist, area, img_of, n_segments, n_truth_labels,
+                       reinterpret_cast<unsigned long long *>(under), reinterpret_cast<unsigned long long *>(under_np));
+    GCS_CHECK_LAUNCH("gcs_score_batch_resident");
+    return GCS_OK;
 }

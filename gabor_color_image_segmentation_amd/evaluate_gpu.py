@@ -141,7 +141,7 @@ def all_scores_device(labels, segments_truth) -> dict:
     return out
 
 
-def all_scores_batch_device(labels, truth, first, img_of, n_truth, n_segments=None) -> list:
+def all_scores_batch_device(labels, truth, first=None, img_of=None, n_truth=None, n_segments=None) -> list:
     """Every number of ``evaluate.metrics.get_metrics()`` for a whole batch of device label maps in THREE launches
     (boundary maps, boundary counts, region tables) and one device-to-host copy per table, instead of a scoring call
     and two host round trips per image (metrics.py:58-201 loops over images in script.py:22).
@@ -150,6 +150,8 @@ def all_scores_batch_device(labels, truth, first, img_of, n_truth, n_segments=No
     layout built by hand): all annotator maps of image 0, then of image 1, ...; n_segments: max label + 1 over the
     batch (default: read from the labels; metrics.py:51 per image is the image's own max + 1, applied below)."""
     import torch
+    if isinstance(truth, DeviceTruth):                       # resident ground truth (round 5): nothing of it is uploaded or re-derived
+        return all_scores_batch_resident(labels, truth, n_segments)
     lib = _lib.load()
     if labels.dtype != torch.int32 or labels.dim() != 3:
         raise ValueError("labels must be a (B,H,W) int32 tensor")
@@ -194,3 +196,180 @@ def all_scores_batch_device(labels, truth, first, img_of, n_truth, n_segments=No
         res["density"] = float(c[0]) / float(h * w)
         out.append(res)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Resident ground truth (round 5). metrics.py:48-49 derives find_boundaries(truth) anew for every image it scores and
+# groundtruth.py:44-48 rescans the split directories per id; round 4's batched scorer still uploaded the annotator maps (40 MB per
+# 24 images) and re-derived their boundary / dilated planes on every call - 67 % of a segment + score loop. The maps are
+# constants of the data set: a DeviceTruth holds them on the device once, as uint8 maps (region tables) and as bit planes of
+# bd(T) and dil5(bd(T)) with the counts sum bd(T) (gcs_truth_prepare), and a scoring call touches nothing else of them.
+
+class DeviceTruth:
+    """The annotator maps of a list of equally shaped images, resident on a device in the form the scorer consumes.
+
+    Build with ``DeviceTruth(truth, first, img_of, n_truth, device)`` from a ``PackedTruth.stack(ids)`` tuple, or
+    ``PackedTruth.to_device(ids, device)``. Pass it to ``all_scores_batch_device(labels, device_truth)``."""
+
+    def __init__(self, truth, first, img_of, n_truth, device="cuda"):
+        import torch
+        lib = _lib.load()
+        truth = np.ascontiguousarray(truth, np.uint16)
+        self.t, self.h, self.w = (int(x) for x in truth.shape)
+        self.first = np.ascontiguousarray(first, np.int32)
+        self.img_of = np.ascontiguousarray(img_of, np.int32)
+        self.b = len(self.first) - 1
+        if int(self.first[-1]) != self.t or len(self.img_of) != self.t:
+            raise ValueError("first / img_of do not describe the truth stack")
+        if np.any(np.diff(self.first) <= 0):
+            raise ZeroDivisionError("an image has no annotator maps (metrics.py:74 divides by len(img_truth))")
+        self.n_truth = np.asarray(n_truth, np.int64)
+        self.stride = int(self.n_truth.max())
+        self.a_max = int(np.diff(self.first).max())
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:           # 'cuda' -> the current device, so that it compares equal to a tensor's
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        with torch.cuda.device(dev):
+            t16 = torch.from_numpy(truth.view(np.int16)).to(dev)
+            self.planes = torch.empty(lib.gcs_bit_planes_bytes(self.t, self.h, self.w), dtype=torch.uint8, device=dev)
+            self.bd_counts = torch.empty(self.t, dtype=torch.int64, device=dev)
+            self.u8 = self.stride <= 256                       # BSD500: the largest annotator label is 208
+            self.maps = torch.empty((self.t, self.h, self.w), dtype=torch.uint8, device=dev) if self.u8 else t16
+            _lib.check(lib.gcs_truth_prepare(t16.data_ptr(), self.t, self.h, self.w, self.planes.data_ptr(),
+                                             self.bd_counts.data_ptr(), self.maps.data_ptr() if self.u8 else None,
+                                             torch.cuda.current_stream(dev).cuda_stream), "gcs_truth_prepare")
+            self.first_d = torch.from_numpy(self.first).to(dev)
+            self.img_of_d = torch.from_numpy(self.img_of).to(dev)
+            torch.cuda.current_stream(dev).synchronize()       # t16 may go (uint8 case): the kernels that read it are done
+        self._out = {}                                         # per n_seg: (device result block, pinned host block, views)
+
+    def _buffers(self, n_seg):
+        """ONE device block for everything a call returns (counts | under | under_np | seg_max | area | perim) and its pinned
+        mirror: one device-to-host copy of a few KB and one synchronisation per call instead of five; the contingency tables
+        stay on the device (gcs_region_reduce takes the two sums metrics.py:128-140 needs out of them)."""
+        import torch
+        ent = self._out.get(n_seg)
+        if ent is None:
+            b, t = self.b, self.t
+            sizes = [("counts", (b + 3 * t) * 8), ("under", t * 8), ("under_np", t * 8), ("seg_max", b * 4),
+                     ("area", b * n_seg * 4), ("perim", b * n_seg * 4)]
+            offs, o = {}, 0
+            for name, nbytes in sizes:
+                offs[name] = (o, nbytes)
+                o += (nbytes + 15) // 16 * 16
+            dev_blk = torch.empty(o, dtype=torch.uint8, device=self.device)
+            host_blk = torch.empty(o, dtype=torch.uint8, pin_memory=True)
+            scratch = torch.empty(_lib.load().gcs_bit_planes_bytes(b, self.h, self.w), dtype=torch.uint8, device=self.device)
+            hist = torch.empty(t * n_seg * self.stride, dtype=torch.int32, device=self.device)     # never leaves the device
+            ent = self._out[n_seg] = (dev_blk, host_blk, offs, scratch, hist)
+        return ent
+
+
+def _region_scores_batch(under, under_np, area, perim, first, nx, ny):
+    """``region_scores_from_counts`` for a whole batch: under / under_np uint64 [T] = the integer sums of gcs_region_reduce
+    (metrics.py:129-130, :137-139; exact in any order), area / perim [B][n_seg]. The sums of fractions keep the reference's
+    order, term by term (metrics.py:131, :140, :194-201)."""
+    b = len(first) - 1
+    u_t = under.astype(np.float64) / (nx * ny)
+    unp_t = under_np.astype(np.float64) / (nx * ny)
+    max_area = float(nx * ny)
+    a64 = area.astype(np.int64)
+    per = perim.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        terms = 4 * pi * (a64 / max_area) * a64 / (per * per)                    # metrics.py:199, element by element
+    out = []
+    u_t, unp_t, first = u_t.tolist(), unp_t.tolist(), np.asarray(first).tolist()  # Python floats: the same IEEE doubles, no
+    terms, has = terms.tolist(), (per > 0).tolist()                              # NumPy scalar boxing per addition
+    for i in range(b):
+        t0, t1 = first[i], first[i + 1]
+        under_i = 0.
+        under_np_i = 0.
+        for t in range(t0, t1):                                                  # metrics.py:131,140: += in annotator order
+            under_i += u_t[t]
+            under_np_i += unp_t[t]
+        compactness = 0
+        for term, ok in zip(terms[i], has[i]):                                   # metrics.py:194-201: index order
+            if ok:
+                compactness += term
+        out.append({"underseg": under_i / (t1 - t0), "undersegNP": under_np_i / (t1 - t0), "compactness": float(compactness)})
+    return out
+
+
+class _PendingScores:
+    """Scores of one batch on their way: kernels and the result copy are enqueued, ``result()`` waits for the copy and does the
+    reference's float arithmetic. Submitting the next batch before collecting this one lets its kernels run under that
+    arithmetic (``all_scores_batch_resident`` = submit + result)."""
+
+    def __init__(self, truth, b, h, w, n_seg, host_blk, offs, event):
+        self._a = (truth, b, h, w, n_seg, host_blk, offs, event)
+
+    def result(self) -> list:
+        truth, b, h, w, n_seg, host_blk, offs, event = self._a
+        event.synchronize()
+        raw = host_blk.numpy()
+        view = lambda k, dt: raw[offs[k][0]:offs[k][0] + offs[k][1]].view(dt)
+        counts = view("counts", np.uint64)
+        seg_max = view("seg_max", np.int32)
+        if int(seg_max.max()) >= n_seg:
+            raise ValueError(f"a label map holds label {int(seg_max.max())} but n_segments = {n_seg}")
+        area = view("area", np.int32).reshape(b, n_seg)
+        perim = view("perim", np.int32).reshape(b, n_seg)
+        reg = _region_scores_batch(view("under", np.uint64), view("under_np", np.uint64), area, perim, truth.first, h, w)
+        out = []
+        cf = counts.astype(np.float64).tolist()                      # counts < 2^53: exact; Python floats from here on
+        first = truth.first.tolist()
+        for i in range(b):
+            t0, t1 = first[i], first[i + 1]
+            g = cf[i]
+            recall = 0
+            precision = 0
+            for t in range(t0, t1):                                  # metrics.py:69-74, :88-96 in annotator order
+                recall += cf[b + 3 * t] / cf[b + 3 * t + 1]          # ZeroDivisionError as metrics.py:72
+                precision += cf[b + 3 * t + 2] / g                   # ZeroDivisionError as metrics.py:94
+            recall /= t1 - t0
+            precision /= t1 - t0
+            sm = recall + precision
+            res = {"regions": int(seg_max[i]) + 1, "recall": recall, "precision": precision,
+                   "fmeasure": 0.0 if sm == 0 else 2.0 * precision * recall / sm}
+            res.update(reg[i])
+            res["density"] = g / float(h * w)
+            out.append(res)
+        return out
+
+
+def submit_scores_batch_resident(labels, truth: DeviceTruth, n_segments=None) -> _PendingScores:
+    """Enqueue the scoring of a (B,H,W) int32 device label batch against resident ground truth; ``.result()`` returns what
+    ``all_scores_batch_device`` returns. One result block per (truth, n_segments): collect a submission before submitting the
+    next batch against the SAME DeviceTruth."""
+    import torch
+    lib = _lib.load()
+    if labels.dtype != torch.int32 or labels.dim() != 3:
+        raise ValueError("labels must be a (B,H,W) int32 tensor")
+    b, h, w = labels.shape
+    if (b, h, w) != (truth.b, truth.h, truth.w) or labels.device != truth.device:
+        raise ValueError("label batch does not match the resident truth (images, shape or device)")
+    labels = labels.contiguous()
+    n_seg = int(n_segments) if n_segments is not None else int(labels.max().item()) + 1
+    dev_blk, host_blk, offs, scratch, hist_d = truth._buffers(n_seg)
+    base = dev_blk.data_ptr()
+    ptr = {k: base + o for k, (o, _) in offs.items()}
+    with torch.cuda.device(truth.device):
+        stream = torch.cuda.current_stream(truth.device)
+        _lib.check(lib.gcs_score_batch_resident(labels.data_ptr(), truth.planes.data_ptr(), truth.bd_counts.data_ptr(),
+                                                truth.maps.data_ptr(), 1 if truth.u8 else 0, truth.first_d.data_ptr(),
+                                                truth.img_of_d.data_ptr(), b, truth.t, truth.a_max, h, w, n_seg, truth.stride,
+                                                scratch.data_ptr(), hist_d.data_ptr(), ptr["counts"], ptr["seg_max"], ptr["area"],
+                                                ptr["perim"], ptr["under"], ptr["under_np"], stream.cuda_stream),
+                   "gcs_score_batch_resident")
+        host_blk.copy_(dev_blk, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(stream)
+    return _PendingScores(truth, b, h, w, n_seg, host_blk, offs, event)
+
+
+def all_scores_batch_resident(labels, truth: DeviceTruth, n_segments=None) -> list:
+    """``all_scores_batch_device`` on resident ground truth: kernels on bit planes and uint8 maps, the tables reduced on the
+    device, ONE device-to-host copy of a few KB. ``n_segments``: an upper bound of max label + 1 over the batch (the
+    Segmenter's k); None reads it from the labels (one more synchronisation)."""
+    return submit_scores_batch_resident(labels, truth, n_segments).result()

@@ -85,3 +85,10 @@ class PackedTruth:
             first.append(first[-1] + len(m))
         truth = np.stack(maps)
         return truth, np.array(first, np.int32), np.array(img_of, np.int32), [int(m.max()) + 1 for m in maps]
+
+    def to_device(self, ids, device="cuda"):
+        """The annotator maps of ``ids`` (one image shape) resident on ``device`` in the scorer's form: uint8 maps, bit planes
+        of their thick boundaries and of the 5x5 dilation, the boundary counts (``evaluate_gpu.DeviceTruth``). What
+        /root/reference/BSD_metrics/metrics.py:48-49 and groundtruth.py:44-48 redo per image happens here once per id."""
+        from .evaluate_gpu import DeviceTruth
+        return DeviceTruth(*self.stack(ids), device=device)

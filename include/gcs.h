@@ -34,7 +34,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 16
+#define GCS_ABI_VERSION 17
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
@@ -185,6 +185,26 @@ size_t gcs_boundary_batch_scratch_bytes(int B, int T, int H, int W);
 int gcs_boundary_counts_batch(const int32_t *labels_dev, const uint16_t *truth_dev, const int32_t *img_of_dev, int B, int T,
                               int H, int W, void *scratch_dev, uint64_t *counts_dev, gcs_stream_t stream);
 
+/* ---- boundary scoring on RESIDENT ground truth (ABI 17) -------------------------------------- */
+
+/* The annotator maps are constants of the data set: /root/reference/BSD_metrics/metrics.py:48-49 re-derives
+ * find_boundaries(truth) for every image it scores and groundtruth.py:44-48 rescans the directories per id. gcs_truth_prepare
+ * does that work ONCE per annotator map: truth_dev uint16 [T][H][W] -> planes_dev, gcs_bit_planes_bytes(T, H, W) bytes of BIT
+ * planes (rows of 64-bit words, bit i of word w = pixel 64 w + i; all thick-boundary planes bd(T_t), then all 5x5-dilated planes),
+ * bd_counts_dev uint64 [T] = sum bd(T_t) (the recall denominators, metrics.py:72), and - when truth8_dev is not NULL and every
+ * label is below 256 (BSD500: at most 208) - the maps narrowed to uint8 [T][H][W] for gcs_region_counts_batch_u8. The caller
+ * keeps all of it on the device for as long as it scores images of these ids. */
+size_t gcs_bit_planes_bytes(int M, int H, int W);
+int gcs_truth_prepare(const uint16_t *truth_dev, int T, int H, int W, void *planes_dev, uint64_t *bd_counts_dev,
+                      uint8_t *truth8_dev, gcs_stream_t stream);
+
+/* gcs_boundary_counts_batch on prepared annotator planes: the same counts_dev uint64 [B + 3T] (every element written, no
+ * atomics), from the bit planes of the B label maps (scratch_dev: gcs_bit_planes_bytes(B, H, W)) ANDed with the resident planes.
+ * seg_max_dev int32 [B] (may be NULL): the largest label of each map (metrics.py:51 wants max + 1). */
+int gcs_boundary_counts_resident(const int32_t *labels_dev, const void *truth_planes_dev, const uint64_t *truth_bd_counts_dev,
+                                 const int32_t *img_of_dev, int B, int T, int H, int W, void *scratch_dev, uint64_t *counts_dev,
+                                 int32_t *seg_max_dev, gcs_stream_t stream);
+
 /* ---- region tables of one image ------------------------------------------ */
 
 /* Integer part of /root/reference/BSD_metrics/metrics.py:102-146 (undersegmentation: the label x annotator
@@ -204,6 +224,28 @@ int gcs_region_counts(const int32_t *labels_dev, const uint16_t *truth_dev, int 
 int gcs_region_counts_batch(const int32_t *labels_dev, const uint16_t *truth_dev, const int32_t *first_dev, int B, int T,
                             int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist_dev,
                             uint32_t *area_dev, uint32_t *perim_dev, gcs_stream_t stream);
+
+/* What metrics.py:128-140 takes from the tables of gcs_region_counts_batch, per annotator map t of image img_of[t]:
+ * under_dev[t] = sum_seg (area[seg] - max_col hist[t][seg][col]) (metrics.py:129-130) and under_np_dev[t] = sum_seg sum_col
+ * min(hist, rowsum - hist) (metrics.py:137-139), uint64 [T] each, integers. The host divides by H * W and averages over the
+ * annotators in the reference's order without ever fetching the tables. */
+int gcs_region_reduce(const uint32_t *hist_dev, const uint32_t *area_dev, const int32_t *img_of_dev, int T, int n_segments,
+                      int n_truth_labels, uint64_t *under_dev, uint64_t *under_np_dev, gcs_stream_t stream);
+
+/* gcs_region_counts_batch on annotator maps narrowed to uint8 by gcs_truth_prepare (n_truth_labels <= 256): half the bytes. */
+int gcs_region_counts_batch_u8(const int32_t *labels_dev, const uint8_t *truth8_dev, const int32_t *first_dev, int B, int T,
+                               int max_annotators, int H, int W, int n_segments, int n_truth_labels, uint32_t *hist_dev,
+                               uint32_t *area_dev, uint32_t *perim_dev, gcs_stream_t stream);
+
+/* Everything metrics.get_metrics() (metrics.py:246-255) needs of a batch, on resident ground truth, in one call (six launches:
+ * gcs_boundary_counts_resident + gcs_region_counts_batch[_u8] + gcs_region_reduce with their zeroing folded into one launch). truth_maps_dev: the uint8 (truth_is_u8 != 0) or uint16 annotator maps; scratch_dev:
+ * gcs_bit_planes_bytes(B, H, W); hist_dev [T][n_segments][n_truth_labels] is scratch the caller may keep on the device; the other
+ * outputs as documented at the three calls. */
+int gcs_score_batch_resident(const int32_t *labels_dev, const void *truth_planes_dev, const uint64_t *truth_bd_counts_dev,
+                             const void *truth_maps_dev, int truth_is_u8, const int32_t *first_dev, const int32_t *img_of_dev, int B,
+                             int T, int max_annotators, int H, int W, int n_segments, int n_truth_labels, void *scratch_dev,
+                             uint32_t *hist_dev, uint64_t *counts_dev, int32_t *seg_max_dev, uint32_t *area_dev, uint32_t *perim_dev,
+                             uint64_t *under_dev, uint64_t *under_np_dev, gcs_stream_t stream);
 
 /* ---- connected regions (SPEC.md §7) -------------------------------------- */
 

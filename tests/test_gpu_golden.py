@@ -213,7 +213,10 @@ def test_bsd_val_boundary_f_gate(seg):
         host = labs.cpu().numpy()
         for b, i in enumerate(group):
             assert np.array_equal(host[b], pack["labels_" + i]), i
-        for i, g in zip(group, all_scores_batch_device(labs, *pt.stack(group))):
+        scored = all_scores_batch_device(labs, *pt.stack(group))
+        # resident ground truth (prepared once per group, nothing uploaded per call), n_segments = the plan's k: the same floats
+        assert all_scores_batch_device(labs, pt.to_device(group), n_segments=seg.k) == scored
+        for i, g in zip(group, scored):
             ref = doc["per_id"][i]["v2"]
             assert g["regions"] == ref["regions"]
             for key in ("recall", "precision", "fmeasure", "density"):

@@ -122,10 +122,16 @@ def test_batched_gpu_scorer_equals_the_reference_numbers_on_the_golden_maps(buil
     maps = np.load(os.path.join(GOLD, "scoring_maps.npz"))
     scores = json.load(open(os.path.join(GOLD, "scoring_golden.json")))
     pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    resident_truth = {}
     for ids in (["100075", "100098"], ["100080"]):                       # one batch per image shape
         for name in ("oracle", "halves", "blocks", "slic"):
             labs = np.stack([_maps(i, inp, path, maps)[name] for i in ids])
-            got = all_scores_batch_device(torch.from_numpy(np.ascontiguousarray(labs)).cuda(), *pt.stack(ids))
+            dev = torch.from_numpy(np.ascontiguousarray(labs)).cuda()
+            got = all_scores_batch_device(dev, *pt.stack(ids))
+            # the same through the RESIDENT ground truth (bit planes + uint8 maps prepared once: gcs_truth_prepare,
+            # gcs_boundary_counts_resident, gcs_region_counts_batch_u8): identical numbers, float for float
+            resident = resident_truth.setdefault(tuple(ids), pt.to_device(ids))
+            assert all_scores_batch_device(dev, resident) == got, (ids, name)
             for i, g in zip(ids, got):
                 ref = scores[i + "/" + name]
                 assert g["regions"] == ref["regions"], (i, name)
@@ -151,10 +157,13 @@ def test_batched_gpu_scorer_on_sixty_further_ids_equals_the_host_mirror(built):
     for group in (land[:20], land[20:], port):
         h, w = pt.shape(group[0])
         stack = pt.stack(group)
+        resident = pt.to_device(group)                                    # prepared ONCE per group, scored three times
         for v in range(3):
             labs = np.stack([_label_candidates(h, w, seed=int(i))[v] for i in group])
             dev = torch.from_numpy(labs).cuda()
             got = all_scores_batch_device(dev, *stack)
+            assert all_scores_batch_device(dev, resident) == got, (group[0], v)      # resident truth: the same floats
+            assert all_scores_batch_device(dev, resident, n_segments=int(labs.max()) + 1) == got
             for b, i in enumerate(group):
                 if (b + v) % 5 == 0:                                   # the host loops are slow: every 5th (id, map) pair
                     m = metrics(np.zeros((h, w, 3), np.uint8), labs[b], pt[i])
@@ -169,3 +178,71 @@ def test_batched_gpu_scorer_on_sixty_further_ids_equals_the_host_mirror(built):
                 if b % 7 == 0:
                     assert got[b] == all_scores_device(dev[b], pt[i]), (i, v)
     assert checked >= 36
+
+
+def test_resident_truth_bit_planes_equal_scipy(built):
+    """gcs_truth_prepare against the scipy restatement of the reference's stencils (evaluate.find_boundaries /
+    _dilate(., 5): metrics.py:49, :69, :93): every bit of both planes, the boundary counts and the uint8 maps, on shapes whose width is
+    and is not a multiple of 64 and whose boundaries touch every border."""
+    import torch
+    from gabor_color_image_segmentation_amd import evaluate as ev
+    from gabor_color_image_segmentation_amd.evaluate_gpu import DeviceTruth
+    rng = np.random.default_rng(3)
+    for h, w in ((321, 481), (37, 64), (5, 130), (70, 63)):
+        maps = []
+        for t in range(3):
+            pts = rng.uniform(0, 1, (6 + t, 2)) * [h, w]
+            yy, xx = np.mgrid[:h, :w]
+            maps.append((np.argmin((yy[..., None] - pts[:, 0]) ** 2 + (xx[..., None] - pts[:, 1]) ** 2, axis=2) + 1).astype(np.uint16))
+        maps[1][0, :] = 9; maps[1][:, -1] = 11; maps[2][-1, -1] = 7         # boundaries on the borders and in the last bit
+        truth = np.stack(maps)
+        dt = DeviceTruth(truth, [0, 2, 3], [0, 0, 1], [int(m.max()) + 1 for m in maps])
+        wp = (w + 63) // 64
+        planes = dt.planes.cpu().numpy().view(np.uint64).reshape(2, 3, h, wp)
+        bits = np.unpackbits(planes.view(np.uint8), axis=-1, bitorder="little").reshape(2, 3, h, wp * 64)
+        assert not bits[..., w:].any()                                     # nothing beyond the image's last column
+        for t in range(3):
+            bd = ev.find_boundaries(truth[t])
+            assert np.array_equal(bits[0, t, :, :w].astype(bool), bd), (h, w, t)
+            assert np.array_equal(bits[1, t, :, :w].astype(bool), ev._dilate(bd, 5)), (h, w, t)
+            assert int(dt.bd_counts[t].item()) == int(bd.sum())
+        assert dt.u8 and np.array_equal(dt.maps.cpu().numpy(), truth.astype(np.uint8))
+
+
+def test_the_fused_resident_scorer_equals_its_three_parts(built):
+    """gcs_score_batch_resident (five launches: one zeroing launch, label planes dilated inline) against the three entry points it
+    fuses - gcs_boundary_counts_resident (dilated label planes from their own launch), gcs_region_counts_batch_u8 and
+    gcs_region_reduce - and gcs_region_reduce against NumPy on the tables: every output word equal."""
+    import torch
+    from gabor_color_image_segmentation_amd import _lib
+    from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
+    lib = _lib.load()
+    pt = PackedTruth(os.path.join(GOLD, "bsd500_truth.npz"))
+    group = [i for i in pt.ids if pt.shape(i) == (481, 321)][:5]
+    dt = pt.to_device(group)
+    b, t, h, w, n_seg = dt.b, dt.t, dt.h, dt.w, 9
+    labs = torch.from_numpy(np.stack([_label_candidates(h, w, seed=int(i))[2] for i in group])).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    z = lambda n, dtype: torch.full((n,), -1, dtype=dtype, device="cuda")               # outputs start dirty: nothing may rely on zeros
+    scratch = torch.empty(lib.gcs_bit_planes_bytes(b, h, w), dtype=torch.uint8, device="cuda")
+    hist, counts, smax = z(t * n_seg * dt.stride, torch.int32), z(b + 3 * t, torch.int64), z(b, torch.int32)
+    area, perim, under, under_np = z(b * n_seg, torch.int32), z(b * n_seg, torch.int32), z(t, torch.int64), z(t, torch.int64)
+    _lib.check(lib.gcs_score_batch_resident(labs.data_ptr(), dt.planes.data_ptr(), dt.bd_counts.data_ptr(), dt.maps.data_ptr(), 1,
+                                            dt.first_d.data_ptr(), dt.img_of_d.data_ptr(), b, t, dt.a_max, h, w, n_seg, dt.stride,
+                                            scratch.data_ptr(), hist.data_ptr(), counts.data_ptr(), smax.data_ptr(), area.data_ptr(),
+                                            perim.data_ptr(), under.data_ptr(), under_np.data_ptr(), stream), "fused")
+    hist2, counts2, smax2 = z(t * n_seg * dt.stride, torch.int32), z(b + 3 * t, torch.int64), z(b, torch.int32)
+    area2, perim2, under2, under_np2 = z(b * n_seg, torch.int32), z(b * n_seg, torch.int32), z(t, torch.int64), z(t, torch.int64)
+    _lib.check(lib.gcs_boundary_counts_resident(labs.data_ptr(), dt.planes.data_ptr(), dt.bd_counts.data_ptr(), dt.img_of_d.data_ptr(),
+                                                b, t, h, w, scratch.data_ptr(), counts2.data_ptr(), smax2.data_ptr(), stream), "counts")
+    _lib.check(lib.gcs_region_counts_batch_u8(labs.data_ptr(), dt.maps.data_ptr(), dt.first_d.data_ptr(), b, t, dt.a_max, h, w, n_seg,
+                                              dt.stride, hist2.data_ptr(), area2.data_ptr(), perim2.data_ptr(), stream), "regions")
+    _lib.check(lib.gcs_region_reduce(hist2.data_ptr(), area2.data_ptr(), dt.img_of_d.data_ptr(), t, n_seg, dt.stride,
+                                     under2.data_ptr(), under_np2.data_ptr(), stream), "reduce")
+    for a, c in ((hist, hist2), (counts, counts2), (smax, smax2), (area, area2), (perim, perim2), (under, under2), (under_np, under_np2)):
+        assert torch.equal(a, c)
+    assert smax.cpu().tolist() == [int(l.max()) for l in labs.cpu()]
+    hh = hist.cpu().numpy().reshape(t, n_seg, dt.stride).astype(np.int64)
+    ar = area.cpu().numpy().reshape(b, n_seg).astype(np.int64)[dt.img_of]
+    assert np.array_equal(under.cpu().numpy(), (ar - hh.max(axis=2)).sum(axis=1))
+    assert np.array_equal(under_np.cpu().numpy(), np.minimum(hh, hh.sum(axis=2, keepdims=True) - hh).sum(axis=(1, 2)))

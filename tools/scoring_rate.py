@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the batched GPU scorer (gcs_boundary_counts_batch + gcs_region_counts_batch behind
-evaluate_gpu.all_scores_batch_device) and of the segment + score loop (`examples/bsd_eval.py --val`) on the 24 packed BSD500
+evaluate_gpu.all_scores_batch_device on resident ground truth, evaluate_gpu.DeviceTruth) and of the segment + score loop (`examples/bsd_eval.py --val`) on the 24 packed BSD500
 val images: label maps stay on the device, ground truth comes from the 500-id pack. Prints one JSON line; `bench.py` embeds
 the same figures (`scoring`)."""
 import json, os, sys, time
@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gabor_color_image_segmentation_amd import Segmenter
-from gabor_color_image_segmentation_amd.evaluate_gpu import all_scores_batch_device
+from gabor_color_image_segmentation_amd.evaluate_gpu import submit_scores_batch_resident
 from gabor_color_image_segmentation_amd.groundtruth import PackedTruth
 
 
@@ -23,15 +23,18 @@ def measure(seg=None, reps=5):
     for shape in sorted({pack["img_" + i].shape[:2] for i in ids}):
         g = [i for i in ids if pack["img_" + i].shape[:2] == shape]
         imgs = torch.from_numpy(np.stack([pack["img_" + i] for i in g])).cuda()
-        groups.append((g, imgs, truth.stack(g)))
+        groups.append((g, imgs, truth.to_device(g)))      # resident ground truth: prepared once per shape group, kept on the device
     n_img = len(ids)
-    n_maps = sum(int(st[0].shape[0]) if hasattr(st[0], "shape") else 0 for _, _, st in groups)
+    n_maps = sum(st.t for _, _, st in groups)
 
     def seg_all():
         return [seg.segment_device(imgs) for _, imgs, _ in groups]
 
     def score_all(labs):
-        return [all_scores_batch_device(l, *st) for l, (_, _, st) in zip(labs, groups)]
+        # every group's kernels are enqueued before the first result is collected: the second group's kernels run under the
+        # first group's host arithmetic
+        pending = [submit_scores_batch_resident(l, st, n_segments=seg.k) for l, (_, _, st) in zip(labs, groups)]
+        return [p.result() for p in pending]
     labs = seg_all(); score_all(labs); torch.cuda.synchronize()          # warm-up (workspaces, truth upload paths)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -50,7 +53,8 @@ def measure(seg=None, reps=5):
                 loop_ms=round(t_loop * 1e3, 3), scoring_images_s=round(n_img / t_score, 1),
                 segment_images_s=round(n_img / t_seg, 1), bsd_eval_val_images_s=round(n_img / t_loop, 1),
                 scoring_share_of_loop=round(t_score / t_loop, 3),
-                note="24 BSD500 val images (two shape groups), device-resident label maps, batched boundary + region kernels, "
+                note="24 BSD500 val images (two shape groups), device-resident label maps AND ground truth (annotator bit planes / "
+                     "uint8 maps prepared once: gcs_truth_prepare), boundary + region kernels, one device-to-host copy per group, "
                      "host float arithmetic of metrics.py:58-201 included; per-image codebooks")
 
 
