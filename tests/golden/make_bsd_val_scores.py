@@ -36,6 +36,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 N_PACK = 24
 K, N_ITER, N_SCALES, N_ORIENT = 8, 10, 4, 6
 F_MAX, RATIO = 0.4, math.sqrt(2.0)
+STUDY_V3 = bool(os.environ.get('GCS_STUDY_V3'))       # see one_image
 
 
 def r1_bank():
@@ -97,6 +98,22 @@ def one_image(i):
     maps = {}
     tapq, shift = spec_oracle.bank()
     maps['v2'] = c_oracle.segment_batch(img[None], tapq.astype(np.int16), shift, N_ORIENT, K, N_ITER)[0]
+    if STUDY_V3:
+        # design study only (tools/design/separable_study.py): the separable SPEC-v3 CANDIDATE beside v2, nothing else; the
+        # result goes to bsd_val_scores_v3.json, the goldens are not touched
+        sys.path.insert(0, os.path.join(REPO, 'tools', 'design'))
+        import separable_study
+        maps['v3'] = separable_study.segment_v3(img, K, N_ITER, N_ORIENT)
+        res = {}
+        for name, lab in maps.items():
+            m = metrics(img, lab.astype(np.int32), segs)
+            m.set_boundary_recall()
+            m.set_boundary_precision()
+            r, p = float(m.recall), float(m.precision)
+            res[name] = {'regions': float(m.n_segments), 'recall': r, 'precision': p,
+                         'fmeasure': 0.0 if r + p == 0 else 2.0 * p * r / (p + r)}
+        print(i, ' '.join('%s F=%.4f' % (n, res[n]['fmeasure']) for n in res), '%.0fs' % (time.time() - t0), flush=True)
+        return i, img, res, maps['v2'].astype(np.uint8)
     tq1, sh1 = r1_bank()
     # n_orient = F puts every filter on pyramid level 0: round 1's full-resolution bank
     maps['r1'] = c_oracle.segment_batch(img[None], tq1, sh1, tq1.shape[0], K, N_ITER)[0]
@@ -135,6 +152,15 @@ def main():
         rows = pool.map(one_image, ids, chunksize=1)
     per_id = {i: res for i, _, res, _ in rows}
     means = {}
+    if STUDY_V3:
+        for name in ('v2', 'v3'):
+            means[name] = {k: float(np.mean([per_id[i][name][k] for i in ids])) for k in ('recall', 'precision', 'fmeasure', 'regions')}
+        json.dump({'split': 'val', 'ids': ids, 'mean': means, 'per_id': per_id,
+                   'scored_by': 'BSD_metrics/metrics.py:58-96 (the reference class)'},
+                  open(os.path.join(out_dir, 'bsd_val_scores_v3.json'), 'w'), indent=1, sort_keys=True)
+        for name in means:
+            print(name, means[name])
+        return
     for name in ('v2', 'r1', 'float', 'slic'):
         means[name] = {k: float(np.mean([per_id[i][name][k] for i in ids])) for k in ('recall', 'precision', 'fmeasure', 'regions')}
         # F of the dataset-mean P and R, beside the mean of the per-image F
