@@ -72,12 +72,20 @@ class _CaptureGuard:
     * graph entries are never dropped where a capture might be open: evicted entries and the entries of a Segmenter that is
       being finalised go through ``retire``, which frees them at once when no capture is open and parks them otherwise
       (drained at the end of the capture, under the lock);
-    * a capture that fails is not silent: ``fell_back`` warns once per plan key."""
+    * a capture that fails is not silent: ``fell_back`` warns once per plan key;
+    * a graph whose capture failed is never destroyed: torch 2.10's ``~CUDAGraph`` throws for it too ("The graph should be
+      registered to the state", tools/dbg/capture_probe.py) - the few hundred bytes stay in ``_failed`` for the life of the process.
+
+    What a thread that is NOT capturing may do beside an open capture was measured on the box (tools/dbg/capture_probe.py,
+    profiles/r5_notes.md): kernel launches, stream / event synchronisation, hipMalloc, pinned allocation and copies are all
+    fine; ``hipDeviceSynchronize`` is refused with hipErrorStreamCaptureUnsupported AND invalidates the other thread's
+    capture - so no path of this package calls ``torch.cuda.synchronize``: every wait is on a stream or an event."""
 
     def __init__(self):
         import threading
         self._lock = threading.Lock()      # not re-entrant: a plan finalised BY the capturing thread must park its graphs too
         self._parked = []            # retired graph entries waiting for the open capture to end
+        self._failed = []            # graphs whose capture was refused or invalidated: kept alive on purpose (see above)
         self._warned = set()
 
     def capture(self, torch, graph, body):
@@ -93,6 +101,7 @@ class _CaptureGuard:
                     body()
                 return True
             except RuntimeError:
+                self._failed.append(graph)
                 return False
             finally:
                 if was_enabled:
@@ -801,7 +810,9 @@ class Segmenter:
                           ws["sums"], raster=dev_out, debug=debug)
                 dev_in.zero_()
                 step()                                     # eager once: first-use work (side-stream creation) outside the capture
-                torch.cuda.synchronize(dev)
+                # (a STREAM wait - the step joins its side stream back into this one: a device-wide synchronize is refused while
+                # any thread of the process captures, and invalidates that thread's capture: _CaptureGuard)
+                torch.cuda.current_stream(dev).synchronize()
                 graph = torch.cuda.CUDAGraph()
                 # capture under the module's guard (_CaptureGuard: serialised, collector off for exactly that long, retired
                 # graphs parked meanwhile); a refused capture (e.g. the caller's own capture is open on this thread) is reported
@@ -809,7 +820,7 @@ class Segmenter:
                 if not _CAPTURES.capture(torch, graph, step):
                     _CAPTURES.fell_back(key, "torch.cuda.graph raised RuntimeError")
                     graph = None
-                    torch.cuda.synchronize(dev)
+                    torch.cuda.current_stream(dev).synchronize()
                 ent = dict(graph=graph, step=step, ws=ws, dev_in=dev_in, dev_out=dev_out, pin_in=pin_in, scratch=scratch)
                 if len(self._graphs) >= 4:                 # evicted plans leave through the guard: never inside an open capture
                     _CAPTURES.retire([self._graphs.pop(next(iter(self._graphs)))])
