@@ -871,13 +871,13 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     //      that hold it read a zero slot of their own (NV_APAT_SLOTS).
     const int a_jj = (lane & 31) >> 2;
     const int a_slot = 32 * (lane >> 5) + 16 * (__builtin_popcount(a_jj) & 1) + 4 * (a_jj >> 1) + (lane & 3);
-    if (wave == 0) {
+    if (wave < NL) {                                         // one level per wave
         const int r = lane & 31, h = lane >> 5;
         const int jj = r >> 2, pat = r & 3;
         const unsigned msk = pat == 0 ? 0x00ff00ffu : pat == 1 ? 0xffffffffu : pat == 2 ? 0xff00ff00u : 0u;
         const unsigned sel = pat == 1 ? 0x02030001u : 0x03020100u;
-#pragma unroll
-        for (int L = 0; L < NL; ++L)
+        {
+            const int L = wave;
 #pragma unroll
             for (int kk = 0; kk < NV_KS; ++kk) {
                 const v4i w = *reinterpret_cast<const v4i *>(&cs[(jj * 4 + L) * NV_DL + 16 * kk + 8 * h]);
@@ -886,6 +886,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
                 for (int e = 0; e < 4; ++e) f[e] = (int)(__builtin_amdgcn_perm(0u, (unsigned)w[e], sel) & msk);
                 s_apat[(L * NV_KS + kk) * NV_APAT_SLOTS + a_slot] = f;   // (pattern 3: msk == 0, f == 0)
             }
+        }
     }
     __syncthreads();                                   // scratch reads done: the tile buffer is free
     v4i accu[NL][NV_UT];
@@ -1132,12 +1133,20 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     }
     if (!do_acc) return;
 
-    // ---- fold: voting pixel counts first, then one level at a time through the tile buffer ([4 waves][16 rows][48 planes] ints;
-    //      row 2 j + t = byte t of cluster j)
+    // ---- fold, every level at once: the whole LDS image is free now, so each wave parks all its accumulators ([wave][level][16 rows]
+    //      [48 planes] ints; row 2 j + t = byte t of cluster j) and its voting pixel counts, two barriers, and the row is written in
+    //      LOGICAL feature order (consecutive threads = consecutive 8-byte elements of the partial row). The first round-5 build folded
+    //      level by level through the tile buffer: eight barriers and stores in physical plane order.
     constexpr int RW = NV_UT * 16;
-    int *red = reinterpret_cast<int *>(s_tile);
-    int *s_cnt = red + 4 * 16 * RW;                               // [wave][K-group][row]
-    static_assert((4 * 16 * RW + 4 * 4 * 16) * 4 <= TILE_B, "fold scratch exceeds the tile buffer");
+    int *red = reinterpret_cast<int *>(s_mem);
+    int *s_cnt = red + 4 * NL * 16 * RW;                          // [wave][K-group][row]
+    static_assert((4 * NL * 16 * RW + 4 * 4 * 16) * 4 <= NJ_O, "fold scratch exceeds the LDS image in front of s_nj");
+#pragma unroll
+    for (int L = 0; L < NL; ++L)
+#pragma unroll
+        for (int nt = 0; nt < NV_UT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((wave * NL + L) * 16 + 4 * ukg + e) * RW + 16 * nt + um] = accu[L][nt][e];
     s_cnt[(wave * 4 + ukg) * 16 + um] = cntacc;
     __syncthreads();
     if (tid < 8) {
@@ -1145,34 +1154,28 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         for (int w = 0; w < 16; ++w) c += s_cnt[w * 16 + 2 * tid];
         s_nj[tid] = c;
     }
-#pragma unroll
-    for (int L = 0; L < NL; ++L) {
-        __syncthreads();                                          // previous level's reads (and s_nj) done
-#pragma unroll
-        for (int nt = 0; nt < NV_UT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ukg + e) * RW + 16 * nt + um] = accu[L][nt][e];
-        __syncthreads();
-        const int DLv = lo.DL[L];
-        for (int i = tid; i < K * DLv; i += 256) {
-            const int j = i / DLv, pl = i % DLv;
+    __syncthreads();
+    for (int i = tid; i < K * D1; i += 256) {
+        const int j = i / D1, e = i - j * D1;                     // e = LOGICAL feature (or D = the count)
+        const long long nj = s_nj[j];
+        long long out = nj;
+        if (e < D) {
+            const int pe = gcs_plane_of_logical(lo, e);
+            const int L = gcs_level_of_plane(lo, pe), pl = pe - lo.row0[L];
             long long flo = 0, fhi = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                flo += red[(w * 16 + 2 * j) * RW + pl];
-                fhi += red[(w * 16 + 2 * j + 1) * RW + pl];
+                flo += red[((w * NL + L) * 16 + 2 * j) * RW + pl];
+                fhi += red[((w * NL + L) * 16 + 2 * j + 1) * RW + pl];
             }
             if (L == 0) {                                         // the one-hot digit is -128
                 flo = -flo / 128;
                 fhi = -fhi / 128;
             }
-            const long long nj = s_nj[j];
-            const long long out = (flo + 128 * nj) + 256 * (fhi + 128 * nj);
-            const int e = gcs_logical_of_plane(lo, lo.row0[L] + pl);
-            partials[prow(j * D1 + e)] = (uint64_t)out;
+            out = (flo + 128 * nj) + 256 * (fhi + 128 * nj);
         }
+        partials[prow(i)] = (uint64_t)out;
     }
-    if (tid < K) partials[prow(tid * D1 + D)] = (uint64_t)s_nj[tid];
 }
 
 static size_t assign_lds_bytes(int D, int k, int R) {

@@ -195,5 +195,28 @@ int main() {
         time2([&] { stream_e<1440, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 23 KB tiles, 4 WG/CU, one list of 1024");
         time2([&] { stream_e<1440, 2><<<dim3(512, 1), 256>>>(src, 64 * tpi, 512, out); }, "E: 23 KB tiles, 2 WG/CU, one list of 512");
     }
+    {
+        // round 5: the deep-bank tile (8x8 bank, four levels: 2040 chunks = 32 640 B; 607 tiles per 321x481 image), the same tile
+        // padded to 32 768 B, and the 23 KB tile again - constant fill and (RANDOM_FILL=1) random payload
+        const int tpi = 607;
+        for (int ch : {2040, 2048}) {
+            const size_t b2 = (size_t)64 * tpi * ch * 16;
+            if (b2 > bytes) { printf("buffer too small\n"); return 1; }
+            auto time3 = [&](auto launch, const char *name) {
+                launch(); hipDeviceSynchronize();
+                float best = 1e9, sum = 0;
+                for (int r = 0; r < 10; ++r) { hipEventRecord(s); launch(); hipEventRecord(e); hipEventSynchronize(e); float ms; hipEventElapsedTime(&ms, s, e); if (ms < best) best = ms; sum += ms; }
+                printf("%-56s best %.3f ms %.0f GB/s | mean %.3f ms %.0f GB/s\n", name, best, b2 / best / 1e6, sum / 10, b2 / (sum / 10) / 1e6);
+            };
+            if (ch == 2040) {
+                time3([&] { stream_e<2040, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 32 640 B tiles, 3 WG/CU, one list of 768");
+                time3([&] { stream_e<2040, 2><<<dim3(512, 1), 256>>>(src, 64 * tpi, 512, out); }, "E: 32 640 B tiles, 2 WG/CU, one list of 512");
+                time3([&] { stream_e<2040, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 32 640 B tiles, 4 WG/CU, one list of 1024");
+            } else {
+                time3([&] { stream_e<2048, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 32 768 B tiles, 3 WG/CU, one list of 768");
+                time3([&] { stream_e<2048, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 32 768 B tiles, 4 WG/CU, one list of 1024");
+            }
+        }
+    }
     return 0;
 }
