@@ -829,31 +829,40 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         }
     };
     auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
-    int ltile = g;
-    if (ltile < nlist) stage_load(phys(ltile));
-
-    // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists
+    // ---- centroids -> scratch [8 clusters][4 levels][48 planes] u16, offset-binary, zero where nothing exists. The six gathers of a
+    //      thread go out FIRST, the first tile's eight loads behind them, and only then are the gathers consumed: loads return in
+    //      order, so a gather issued behind the tile (the first round-5 build) waited for the tile's 32 KB as well (stamps: the
+    //      gather loop took 5.6 - 6.7 us of a 10 - 11.6 us prologue).
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
-    static_assert(8 * 4 * NV_DL * 2 <= TILE_B, "centroid scratch exceeds the tile buffer");
-    for (int i = tid; i < 8 * 4 * NV_DL; i += 256) {
+    static_assert(8 * 4 * NV_DL * 2 <= TILE_B && (8 * 4 * NV_DL) % 256 == 0, "centroid scratch: tile buffer, whole rounds");
+    constexpr int NCS = 8 * 4 * NV_DL / 256;
+    unsigned cv[NCS];
+#pragma unroll
+    for (int r = 0; r < NCS; ++r) {
+        const int i = tid + 256 * r;
         const int j = i / (4 * NV_DL), L = (i / NV_DL) & 3, pl = i % NV_DL;
         const bool ok = j < K && L < NL && pl < lo.DL[L];
-        cs[i] = ok ? (uint16_t)(cset[j * D + gcs_logical_of_plane(lo, lo.row0[L] + pl)] ^ 0x8080u) : (uint16_t)0;
+        const int src = ok ? j * D + gcs_logical_of_plane(lo, lo.row0[L < NL ? L : 0] + pl) : 0;
+        cv[r] = (unsigned)cset[src] | (ok ? 0u : 0x10000u);   // (bit 16: nothing exists there)
     }
+    int ltile = g;
+    if (ltile < nlist) stage_load(phys(ltile));
+#pragma unroll
+    for (int r = 0; r < NCS; ++r) cs[tid + 256 * r] = (cv[r] & 0x10000u) ? (uint16_t)0 : (uint16_t)(cv[r] ^ 0x8080u);
     __syncthreads();
     for (int j = tid >> 4; j < 16; j += 16) {                // key base, as in kmeans_pass_mfma_kernel
         const int sub = tid & 15;
         long long nrm = 0, scl = 0, sch = 0;
-        if (j < K && j < 8)
-            for (int d = sub; d < 4 * NV_DL; d += 16) {
-                const int L = d / NV_DL, pl = d % NV_DL;
-                if (L < NL && pl < lo.DL[L]) {
-                    const long long c = cs[j * 4 * NV_DL + d] ^ 0x8080u;
-                    nrm += c * c;
+        if (j < K && j < 8) {
+#pragma unroll
+            for (int L = 0; L < NL; ++L)                       // (levels unrolled: every lo.DL[L] a plain kernel argument)
+                for (int pl = sub; pl < lo.DL[L]; pl += 16) {
+                    const unsigned c = cs[(j * 4 + L) * NV_DL + pl] ^ 0x8080u;
+                    nrm += (long long)((unsigned long long)c * c);
                     scl += c & 255;
                     sch += c >> 8;
                 }
-            }
+        }
 #pragma unroll
         for (int m = 8; m >= 1; m >>= 1) {
             nrm += __shfl_xor(nrm, m);
