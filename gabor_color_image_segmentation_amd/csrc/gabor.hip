@@ -127,18 +127,15 @@ __device__ __forceinline__ void plane_deinterleave4(unsigned d0, unsigned d1, un
     b = __builtin_amdgcn_perm(b23, b01, 0x07060100u) ^ 0x80808080u;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
-                                                          int Hp, int Wp, int8_t *__restrict__ planes,
-                                                          uint8_t *__restrict__ img_out) {
-    static_assert(MODE == 0, "levels >= 1 use gabor_down_kernel");
-    const int b = blockIdx.y;
+// (the body: workgroup bx of gdx of image b, so that a small call can run it beside the level-1 pre-pass in ONE launch)
+__device__ __forceinline__ void gabor_plane_body(int bx, int gdx, int b, const uint8_t *__restrict__ src, int Hs, int Ws, int HL,
+                                                 int WL, int Hp, int Wp, int8_t *__restrict__ planes) {
     const int ng = Wp / 16;                                          // 16-byte groups per plane row
     // interior groups g: level columns 16 g - 7 .. 16 g + 8 all inside [0, WL)
     const int g_lo = 1, g_hi = WL >= 25 ? (WL - 9) / 16 : 0;         // interior: g_lo <= g <= g_hi (none for narrow levels)
     const int n_in = g_hi >= g_lo ? g_hi - g_lo + 1 : 0;
     const int n_bd = ng - n_in;
-    const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    const int tid = bx * 256 + threadIdx.x, nthr = gdx * 256;
     int8_t *pb = planes + (size_t)b * 3 * Hp * Wp;
     const size_t cstride = (size_t)Hp * Wp;
     // ---- interior items, two per thread in flight
@@ -191,6 +188,13 @@ __global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restr
             *reinterpret_cast<v4i *>(dst + c * cstride) = v4i{(int)o[c][0], (int)o[c][1], (int)o[c][2], (int)o[c][3]};
     }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
+                                                          int Hp, int Wp, int8_t *__restrict__ planes,
+                                                          uint8_t *__restrict__ img_out) {
+    static_assert(MODE == 0, "levels >= 1 use gabor_down_kernel");
+    gabor_plane_body((int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, src, Hs, Ws, HL, WL, Hp, Wp, planes);
+}
 
 // Levels >= 1, staged through LDS (same-run rocprofv3: 33 us per 64 images against 47 us for gabor_plane_kernel<1>'s
 // unaligned-dword form and 41 us for one byte load per sample): one workgroup per (padded plane row r, image b); the two
@@ -198,11 +202,9 @@ __global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restr
 // arbitrary byte), then every thread assembles output dwords from LDS bytes. SRC_RGB: level 1 from the interleaved
 // input; otherwise level L > 1 from the compact planar level L-1 image [B][3][Hs][Ws].
 template <bool SRC_RGB>
-__global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restrict__ src, size_t src_bytes, int Hs, int Ws,
-                                                         int HL, int WL, int Hp, int Wp, int8_t *__restrict__ planes,
-                                                         uint8_t *__restrict__ img_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_rows[];
-    const int b = blockIdx.y, r = blockIdx.x;
+__device__ __forceinline__ void gabor_down_body(int r, int b, unsigned char *s_rows, const uint8_t *__restrict__ src,
+                                                size_t src_bytes, int Hs, int Ws, int HL, int WL, int Hp, int Wp,
+                                                int8_t *__restrict__ planes, uint8_t *__restrict__ img_out) {
     const int ly = reflect(r - G_HALO, HL);
     constexpr int NSEG = SRC_RGB ? 1 : 3;                            // planar source: one segment per channel
     const int seg_bytes = SRC_RGB ? Ws * 3 : Ws;
@@ -255,6 +257,23 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
         for (int c = 0; c < 3; ++c)
             *reinterpret_cast<unsigned *>(planes + (((size_t)b * 3 + c) * Hp + r) * Wp + 4 * u4) = o[c];
     }
+}
+template <bool SRC_RGB>
+__global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restrict__ src, size_t src_bytes, int Hs, int Ws,
+                                                         int HL, int WL, int Hp, int Wp, int8_t *__restrict__ planes,
+                                                         uint8_t *__restrict__ img_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_rows[];
+    gabor_down_body<SRC_RGB>((int)blockIdx.x, (int)blockIdx.y, s_rows, src, src_bytes, Hs, Ws, HL, WL, Hp, Wp, planes, img_out);
+}
+// The level-0 and level-1 pre-passes of a two-level bank in ONE launch (small calls: each is a 5 - 7 us launch of its own in
+// front of the bank, script.py:22-30 calls the slot once per image): workgroups [0, n0) run the level-0 body, the rest one
+// padded level-1 row each.
+__global__ __launch_bounds__(256) void gabor_pre01_kernel(const uint8_t *__restrict__ src, size_t src_bytes, int H, int W, int n0,
+                                                          int H0, int W0, int Hp0, int Wp0, int8_t *__restrict__ planes0,
+                                                          int H1, int W1, int Hp1, int Wp1, int8_t *__restrict__ planes1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_rows[];
+    if ((int)blockIdx.x < n0) gabor_plane_body((int)blockIdx.x, n0, (int)blockIdx.y, src, H, W, H0, W0, Hp0, Wp0, planes0);
+    else gabor_down_body<true>((int)blockIdx.x - n0, (int)blockIdx.y, s_rows, src, src_bytes, H, W, H1, W1, Hp1, Wp1, planes1, nullptr);
 }
 
 #ifndef GCS_GABOR_WAVES
@@ -317,7 +336,11 @@ constexpr int G_COPY = 3 * G_LROWS * G_LPITCH;      // bytes of one copy of a ti
 
 template <int MT, int GQ, int KS, int LVL, bool FAST>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
-    GaborLevels G, int FLv, int fbase, int shift, unsigned char *__restrict__ feats, int total_tiles, GaborSlab S) {
+    GaborLevels G, int FLv, int fbase0, int shift, unsigned char *__restrict__ feats, int total_tiles, GaborSlab S) {
+    // blockIdx.y = row-tile GROUP of the launch: group q works on filters fbase0 + 4 MT q .. of every tile of the list (a small call -
+    // one to four BSD images - has fewer tiles than the chip has slots, so its three row tiles run side by side as three groups
+    // of MT = 1 workgroups instead of one after the other in every workgroup; every other launch has one group)
+    const int grp = blockIdx.y, fbase = fbase0 + 4 * MT * grp;
     // Persistent workgroups: the A operand and the biases are loaded ONCE, then the workgroup walks
     // tiles blockIdx.x, +gridDim.x, ... ; the next tile streams into the other LDS buffer by LDS-DMA
     // (global_load_lds: no VGPRs, lands while this tile computes). The tile image is a flat run of
@@ -334,11 +357,15 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     // dynamically indexed by-value kernel argument would be copied to scratch.
     auto level_of = [&](int tile, int from) {
         if constexpr (!FUSED) return 0;
+        if constexpr (LVL == -2) return tile >= G.lv[0].tile_end ? 1 : 0;
         int l = from;
         while (l + 1 < GCS_LEVELS_MAX && tile >= (l == 0 ? G.lv[0].tile_end : l == 1 ? G.lv[1].tile_end : G.lv[2].tile_end)) ++l;
         return l;
     };
-    auto pick = [&](int l) -> GaborLevel { return l == 0 ? G.lv[0] : l == 1 ? G.lv[1] : l == 2 ? G.lv[2] : G.lv[3]; };
+    auto pick = [&](int l) -> GaborLevel {
+        if constexpr (LVL == -2) return l == 0 ? G.lv[0] : G.lv[1];
+        return l == 0 ? G.lv[0] : l == 1 ? G.lv[1] : l == 2 ? G.lv[2] : G.lv[3];
+    };
     static_assert(GCS_LEVELS_MAX == 4, "level_of / pick enumerate four levels");
 
     // the two half tiles (rows y, columns x of their first pixel) of tile `rem` of an image; an absent second half (odd
@@ -403,11 +430,11 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
-                afr[mt][kk] = reinterpret_cast<const v4i *>(v.apack)[((size_t)mt * 8 + kk) * 64 + lane];
+                afr[mt][kk] = reinterpret_cast<const v4i *>(v.apack)[((size_t)(MT * grp + mt) * 8 + kk) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int fp = 0; fp < 2; ++fp) bias_v[mt][fp] = v.bias[4 * mt + 2 * fp + h];
+            for (int fp = 0; fp < 2; ++fp) bias_v[mt][fp] = v.bias[4 * (MT * grp + mt) + 2 * fp + h];
         HL = v.HLm; pitchL = v.pitchLm; htx = v.htx; hcount = v.hcount; tiles_per_image = v.tiles_per_image;
         tile0 = lvl ? pick(lvl - 1).tile_end : 0;
         L = LVL >= 0 ? LVL : v.L;
@@ -552,7 +579,7 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
                         __builtin_nontemporal_store(v4i{(int)w0, (int)w1, (int)w2, (int)w3}, reinterpret_cast<v4i *>(up + o0));
                     });
-                } else if (Lc == 1) {
+                } else if (Lc == 1 || LVL == -2) {
                     const unsigned o0 = lane_off(0), o1 = lane_off(1);
                     const bool has1 = bx0 + 1 < S.bx_n;
                     planes([&](unsigned char *up, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
@@ -866,8 +893,24 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             return gcs_hip_fail(e_, what);                       \
         }                                                        \
     } while (0)
+    // A call so small that the tiles of ALL its levels fit the resident slots at once (one to four BSD images) also takes
+    // the fused list: level 1's tiles then run beside level 0's instead of in a launch of their own behind them (one image:
+    // the two launches take 19 us each, one after the other; the slot is called once per image, script.py:22-30).
+    long long tiles_all = 0;
+    for (int L = 0; L < lo.n_levels; ++L) tiles_all += (long long)B * ((half_tiles(L) + 1) / 2);
+    const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
     // ---- pre-passes: the padded planes of every level (level L >= 2 reads level L-1's compact image)
     for (int L = 0; L < lo.n_levels; ++L) {
+        if (fuse_small && !forked) {                           // a small call: both pre-passes of the two-level bank in one launch
+            if (L == 1) continue;
+            const int n0 = (ws.Hp[0] * (ws.Wp[0] / 16) + 511) / 512;
+            const size_t lds = 2 * (size_t)((W * 3 + 6) & ~3);
+            hipLaunchKernelGGL(gabor_pre01_kernel, dim3(n0 + ws.Hp[1], B), block, lds, stream, img, (size_t)B * H * W * 3, H, W, n0,
+                               ws.HL[0], ws.WL[0], ws.Hp[0], ws.Wp[0], reinterpret_cast<int8_t *>(wsb + ws.plane_off[0]),
+                               ws.HL[1], ws.WL[1], ws.Hp[1], ws.Wp[1], reinterpret_cast<int8_t *>(wsb + ws.plane_off[1]));
+            GCS_GABOR_CHECK("gcs_gabor_features(pad)");
+            continue;
+        }
         int8_t *planes = reinterpret_cast<int8_t *>(wsb + ws.plane_off[L]);
         const int HL = ws.HL[L], WL = ws.WL[L], Hp = ws.Hp[L], Wp = ws.Wp[L];
         // level-0 pre-pass: about two interior items (16 bytes x 3 channels) per thread and loop round
@@ -897,12 +940,6 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         m += mtiles(lo.FL[L]);
     }
     const int mtmax = ksize <= 13 ? GCS_GABOR_MTMAX : 2;     // A operand: MT x KS x 4 VGPRs (84 for 3 x 7, 64 for 2 x 8)
-    // A call so small that the tiles of ALL its levels fit the resident slots at once (one to four BSD images) also takes
-    // the fused list: level 1's tiles then run beside level 0's instead of in a launch of their own behind them (one image:
-    // the two launches take 19 us each, one after the other; the slot is called once per image, script.py:22-30).
-    long long tiles_all = 0;
-    for (int L = 0; L < lo.n_levels; ++L) tiles_all += (long long)B * ((half_tiles(L) + 1) / 2);
-    const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
     auto launch_group = [&](int L0, int &L1) -> int {
         L1 = L0 + 1;
         // fused lists pay ~2 % for level fields that are no longer launch constants and win the small levels' ramp and
@@ -914,10 +951,15 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             if (int rc = join()) return rc;
         // three row tiles only for single launches of level 0 / 1 (compile-time level): with the level a run-time value the
         // store path of every level is live and a third tile's 28 A registers spill
-        const int mtmax_here = (L1 - L0 == 1 && L0 <= 1) ? mtmax : 2;
-        const int passes = (MT + mtmax_here - 1) / mtmax_here, per_pass = (MT + passes - 1) / passes;   // 4 tiles -> 2 + 2, not 3 + 1
+        // (a fused list of exactly levels 0 and 1 - LVL = -2: two store paths - keeps the third tile too)
+        const bool two_fused = lo.n_levels == 2 && L0 == 0 && L1 == 2;
+        const int mtmax_here = ((L1 - L0 == 1 && L0 <= 1) || two_fused) ? mtmax : 2;
+        // a small call (fuse_small) whose filters fill whole row tiles: ONE launch of MT groups of one-tile workgroups (blockIdx.y)
+        const bool grouped = fuse_small && FLg % 4 == 0 && MT > 1;
+        const int passes = grouped ? 1 : (MT + mtmax_here - 1) / mtmax_here;
+        const int per_pass = grouped ? MT : (MT + passes - 1) / passes;   // 4 tiles -> 2 + 2, not 3 + 1
         for (int mt0 = 0; mt0 < MT; mt0 += per_pass) {
-            const int n = MT - mt0 >= per_pass ? per_pass : MT - mt0;
+            const int n = grouped ? 1 : MT - mt0 >= per_pass ? per_pass : MT - mt0;
             // filters of this launch: [4*mt0, min(FL, 4*(mt0+n))) of each level (planes c*FL + f)
             const int fl_here = FLg - 4 * mt0 < 4 * n ? FLg - 4 * mt0 : 4 * n;
             const int gq = (fl_here - 4 * (n - 1) + 1) / 2;
@@ -949,7 +991,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             const GaborSlab slab{lo.bx_n, lo.ntiles, lo.tile_bytes};
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
             const int slots = gcs_cu_count() * 2;
-            const dim3 grid(total_tiles < slots ? total_tiles : slots);
+            const dim3 grid(total_tiles < slots ? total_tiles : slots, grouped ? MT : 1);
 #define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
     hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
                        reinterpret_cast<unsigned char *>(feats), total_tiles, slab)
@@ -969,10 +1011,17 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     } while (0)
             // 7 K-steps need the kernel inside rows 1..13 of the 15-row frame (ksize <= 13)
             if (ksize <= 13) {
-                if (n == 3) {                    // single launch of level 0 or 1 (mtmax_here)
-                    if (gq == 1) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 1, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 1, 7, 1, false); }
-                    else if (shift == 8) { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, true); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, true); }
-                    else { if (L0 == 0) GCS_GABOR_LAUNCH4(3, 2, 7, 0, false); else GCS_GABOR_LAUNCH4(3, 2, 7, 1, false); }
+                if (n == 3) {                    // single launch of level 0 or 1, or the fused list of both (mtmax_here)
+#define GCS_GABOR_LAUNCH3T(GQ_, FA_)                                        \
+    do {                                                                    \
+        if (two_fused) GCS_GABOR_LAUNCH4(3, GQ_, 7, -2, FA_);               \
+        else if (L0 == 0) GCS_GABOR_LAUNCH4(3, GQ_, 7, 0, FA_);             \
+        else GCS_GABOR_LAUNCH4(3, GQ_, 7, 1, FA_);                          \
+    } while (0)
+                    if (gq == 1) GCS_GABOR_LAUNCH3T(1, false);
+                    else if (shift == 8) GCS_GABOR_LAUNCH3T(2, true);
+                    else GCS_GABOR_LAUNCH3T(2, false);
+#undef GCS_GABOR_LAUNCH3T
                 }
                 else if (n == 2) GCS_GABOR_LAUNCH2(2, 7);
                 else GCS_GABOR_LAUNCH2(1, 7);
