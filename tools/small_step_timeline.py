@@ -5,7 +5,8 @@ for f in glob.glob(d+'/**/*kernel_trace.csv',recursive=True): rows+=list(csv.Dic
 ker=sorted((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"][:50]) for r in rows)
 ker=[k for k in ker if 'elementwise' not in k[2]]
 # last occurrence of plane kernel = start of last step
-idx=[i for i,k in enumerate(ker) if 'gabor_plane' in k[2]]
+# the first kernel of a step: the level-0 pre-pass (since round 5, for small calls, gabor_pre01_kernel: both pre-passes in one launch)
+idx=[i for i,k in enumerate(ker) if 'gabor_plane' in k[2] or 'gabor_pre01' in k[2]]
 i0=idx[-2]; i1=idx[-1]
 t0=ker[i0][0]
 prev=None
