@@ -404,6 +404,27 @@ def test_global_codebook_bit_exact(torch_cuda):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("no,ks", [(4, 13), (6, 13), (8, 13), (5, 13), (7, 13), (6, 15), (8, 15), (2, 9)])
+@pytest.mark.parametrize("b,h,w", [(1, 81, 121), (3, 72, 104)])
+def test_small_call_launch_forms_of_two_level_banks(torch_cuda, no, ks, b, h, w):
+    """Round 5: a small call (every tile of both levels fits the resident slots) runs both pre-passes in one launch
+    (gabor_pre01_kernel) and the bank's row tiles side by side as blockIdx.y groups of one launch when the 2 * n_orient filters of a
+    level fill whole row tiles (n_orient 4 / 6 / 8: two / three / four groups; 8-K-step frames for ksize 15); otherwise the fused
+    two-level list of three row tiles (LVL = -2: n_orient 5) or two launches of two (n_orient 7); n_orient 2: one tile, no groups.
+    Features and labels == the oracle, packed edge strips (81 = 8 k + 1, 121 = 8 k + 1) included."""
+    from gabor_color_image_segmentation_amd import Segmenter
+    torch = torch_cuda
+    imgs = _synth(b, h, w, seed=500 + no)
+    seg = Segmenter(n_scales=4, n_orient=no, ksize=ks, k=5, n_iter=3)
+    got = seg.features_device(torch.from_numpy(imgs).cuda()).cpu().numpy().view(np.uint16)
+    tapq, shift = so.bank(4, no, ks)
+    for i in range(b):
+        assert np.array_equal(got[i], so.gabor_features(imgs[i], tapq, shift, no)), (no, ks, i)
+    lab = seg.segment_batch(imgs)
+    for i in range(b):
+        assert np.array_equal(lab[i], so.segment(imgs[i], n_scales=4, n_orient=no, ksize=ks, k=5, n_iter=3)), (no, ks, i)
+
+
 @pytest.mark.parametrize("ns,no,ks,k", [(1, 1, 15, 3), (1, 4, 9, 5), (2, 5, 11, 8), (3, 8, 15, 16), (2, 13, 7, 4),
                                         (3, 9, 15, 4), (1, 43, 11, 5), (8, 8, 15, 8), (8, 8, 15, 13), (3, 23, 9, 16),
                                         (3, 23, 9, 7)])
