@@ -146,9 +146,13 @@ __device__ __forceinline__ void gcs_strip_pixel(const GcsLayout &lo, int blk, in
     const bool right = blk < lo.nmain + lo.nR;
     const int v = blk - lo.nmain - (right ? 0 : lo.nR);
     const int s = 32 * v + 8 * (iy >> 1) + 2 * (ix >> 1);
-    y = right ? s + (iy & 1) : lo.Hm + (iy & 1);
-    x = right ? lo.Wm + (ix & 1) : s + (ix & 1);
-    xlim = right ? lo.W : lo.Wb;
+    // (the fields as VALUES first: hipcc may otherwise fold a select of two kernel-argument loads into ONE vector load from a
+    //  selected address - a global_load_dword + s_waitcnt vmcnt(0) inside the tile loop of a Lloyd pass)
+    const int Hm = __builtin_amdgcn_readfirstlane(lo.Hm), Wm = __builtin_amdgcn_readfirstlane(lo.Wm);
+    const int Wf = __builtin_amdgcn_readfirstlane(lo.W), Wb = __builtin_amdgcn_readfirstlane(lo.Wb);
+    y = right ? s + (iy & 1) : Hm + (iy & 1);
+    x = right ? Wm + (ix & 1) : s + (ix & 1);
+    xlim = right ? Wf : Wb;
 }
 
 // physical plane -> (level, plane in level); logical feature <-> physical plane

@@ -237,6 +237,22 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
 // difference (4 820 / 4 777 vs 4 822 / 4 769 Mpix/s). Slabs the cache can hold a good part of lose with the hint (16 images,
 // 224 MB: 4 007 -> 3 910 Mpix/s; 8 images: 2 996 -> 2 886): the host sets `nt` from the slab size (profiles/r4_notes.md).
 constexpr size_t KP_NT_MIN_SLAB_BYTES = (size_t)512 << 20;
+// Logical feature of plane `pl` of level LL, and its inverse, with the level a COMPILE-TIME constant: `lo` is a by-value kernel
+// argument, and indexing one of its arrays with a per-lane level (gcs_logical_of_plane / gcs_plane_of_logical on a run-time plane)
+// makes hipcc fetch the element from the kernarg segment with a VECTOR load and wait for it - four dependent loads and
+// s_waitcnt vmcnt(0) in front of every centroid gather and every partial-row store of the round-4 kernels (ISA; stamps:
+// profiles/r5_notes.md). The callers unroll over the levels and keep the result of the lane's own level.
+template <int LL>
+__device__ __forceinline__ int kp_logical_of(const GcsLayout &lo, int pl) {
+    const int c = pl / lo.FL[LL];
+    return c * lo.F + 2 * LL * lo.n_orient + (pl - c * lo.FL[LL]);
+}
+// physical plane of logical feature e, or -1 when e is not on level LL (also gives the level: the caller's LL)
+template <int LL>
+__device__ __forceinline__ int kp_plane_on_level(const GcsLayout &lo, int c, int f) {
+    const int fl = f - 2 * LL * lo.n_orient;                  // filter index inside level LL
+    return (LL < lo.n_levels && fl >= 0 && fl < lo.FL[LL]) ? lo.row0[LL] + c * lo.FL[LL] + fl : -1;
+}
 template <typename T>
 __device__ __forceinline__ T kp_load(const T *p, bool nt) {
     return nt ? __builtin_nontemporal_load(p) : *p;
@@ -301,7 +317,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);
     for (int i = tid; i < 8 * KT * KP_ROWS; i += NTHR) {
         const int j = i / KP_ROWS, r = i % KP_ROWS;
-        cs[i] = (j < K && r < D) ? (uint16_t)(cset[j * D + gcs_logical_of_plane(lo, r)] ^ 0x8080u) : (uint16_t)0;
+        int e = 0;                                               // logical feature of physical plane r (kp_logical_of: levels unrolled)
+        if (r >= lo.row0[0] && r < lo.row0[0] + lo.DL[0]) e = kp_logical_of<0>(lo, r - lo.row0[0]);
+        if (lo.n_levels > 1 && r >= lo.row0[1] && r < lo.row0[1] + lo.DL[1]) e = kp_logical_of<1>(lo, r - lo.row0[1]);
+        if (lo.n_levels > 2 && r >= lo.row0[2] && r < lo.row0[2] + lo.DL[2]) e = kp_logical_of<2>(lo, r - lo.row0[2]);
+        if (lo.n_levels > 3 && r >= lo.row0[3] && r < lo.row0[3] + lo.DL[3]) e = kp_logical_of<3>(lo, r - lo.row0[3]);
+        cs[i] = (j < K && r < D) ? (uint16_t)(cset[j * D + e] ^ 0x8080u) : (uint16_t)0;
     }
     __syncthreads();
     // ---- per-cluster key base (exact int64): 16 * (|c|^2 - 2*(offset terms of the -128 digits)) + j.
@@ -651,7 +672,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         const long long nj = folded(j, cnt_bp);
         long long out = nj;
         if (e < D) {
-            const int pe = gcs_plane_of_logical(lo, e);
+            const int c = e / lo.F, f = e - c * lo.F;           // physical plane of logical feature e (levels unrolled)
+            int pe = kp_plane_on_level<0>(lo, c, f);
+            { const int q = kp_plane_on_level<1>(lo, c, f); pe = q >= 0 ? q : pe; }
+            { const int q = kp_plane_on_level<2>(lo, c, f); pe = q >= 0 ? q : pe; }
+            { const int q = kp_plane_on_level<3>(lo, c, f); pe = q >= 0 ? q : pe; }
             out = (folded(j, 2 * pe) + 128 * nj) + 256 * (folded(j, 2 * pe + 1) + 128 * nj);
         }
         partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = (uint64_t)out;
@@ -841,8 +866,14 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     for (int r = 0; r < NCS; ++r) {
         const int i = tid + 256 * r;
         const int j = i / (4 * NV_DL), L = (i / NV_DL) & 3, pl = i % NV_DL;
-        const bool ok = j < K && L < NL && pl < lo.DL[L];
-        const int src = ok ? j * D + gcs_logical_of_plane(lo, lo.row0[L < NL ? L : 0] + pl) : 0;
+        bool ok = false;                                     // (levels unrolled: kp_logical_of)
+        int e = 0;
+        if (L == 0 && pl < lo.DL[0]) { ok = true; e = kp_logical_of<0>(lo, pl); }
+        if (NL > 1 && L == 1 && pl < lo.DL[1]) { ok = true; e = kp_logical_of<1>(lo, pl); }
+        if (NL > 2 && L == 2 && pl < lo.DL[2]) { ok = true; e = kp_logical_of<2>(lo, pl); }
+        if (NL > 3 && L == 3 && pl < lo.DL[3]) { ok = true; e = kp_logical_of<3>(lo, pl); }
+        ok = ok && j < K;
+        const int src = ok ? j * D + e : 0;
         cv[r] = (unsigned)cset[src] | (ok ? 0u : 0x10000u);   // (bit 16: nothing exists there)
     }
     int ltile = g;
@@ -1169,8 +1200,12 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         const long long nj = s_nj[j];
         long long out = nj;
         if (e < D) {
-            const int pe = gcs_plane_of_logical(lo, e);
-            const int L = gcs_level_of_plane(lo, pe), pl = pe - lo.row0[L];
+            const int c = e / lo.F, f = e - c * lo.F;           // level and plane in its level of logical feature e (levels unrolled)
+            int L = 0, pl = 0;
+            { const int q = kp_plane_on_level<0>(lo, c, f); if (q >= 0) { L = 0; pl = q - lo.row0[0]; } }
+            if (NL > 1) { const int q = kp_plane_on_level<1>(lo, c, f); if (q >= 0) { L = 1; pl = q - lo.row0[1]; } }
+            if (NL > 2) { const int q = kp_plane_on_level<2>(lo, c, f); if (q >= 0) { L = 2; pl = q - lo.row0[2]; } }
+            if (NL > 3) { const int q = kp_plane_on_level<3>(lo, c, f); if (q >= 0) { L = 3; pl = q - lo.row0[3]; } }
             long long flo = 0, fhi = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
