@@ -27,6 +27,9 @@ def ins(txt, anchor, stamp, before=True):
 
 # kmeans_pass_mfma_kernel
 head = ins(head, "    uint16_t *cs = reinterpret_cast<uint16_t *>(s_tile);\n    for (int i = tid; i < 8 * KT * KP_ROWS; i += NTHR) {", "    NV_STAMP(0); NV_XCC();\n")
+head = ins(head, "    // ---- per-cluster key base (exact int64)", "    NV_STAMP(3);\n")
+head = ins(head, "    // ---- assign A fragments: row r = 4*jj + pat of tile mt", "    NV_STAMP(4);\n")
+head = ins(head, "    __syncthreads();                                   // scratch reads done: the tile buffer is free again\n", "    NV_STAMP(5);\n")
 head = ins(head, "    __syncthreads();                                   // scratch reads done: the tile buffer is free again\n", "    NV_STAMP(6);\n", before=False)
 head = ins(head, "    if (!do_acc) return;\n    // ---- fold the four waves' accumulators", "    NV_STAMP(8);\n")
 head = ins(head, "        partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = (uint64_t)out;\n    }\n}\n\n// ----------------------------------------------------------------------------"
