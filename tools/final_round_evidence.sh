@@ -21,7 +21,7 @@ rm -rf $O/prof_scoring $O/prof_small $O/prof_gstage
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scoring -- python $R/tools/scoring_rate.py > $O/${TAG}_final_scoring.log 2>&1 \
   && cp $O/prof_scoring/*/*kernel_stats.csv $P/${TAG}_scoring_kernel_stats.csv
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/prof_small -- python $R/tools/small_call_probe.py > $O/${TAG}_final_small.log 2>&1 \
-  && { tail -1 $O/${TAG}_final_small.log; python $R/tools/small_step_timeline.py $O/prof_small; } > $P/${TAG}_small_call_timeline.txt 2>&1
+  && { echo "(rocprofv3 --kernel-trace of tools/small_call_probe.py, last replay of the one-image graph; under the tracer:"; grep "host->host" $O/${TAG}_final_small.log | tail -1; echo ")"; python $R/tools/small_step_timeline.py $O/prof_small; } > $P/${TAG}_small_call_timeline.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/prof_gstage -- python $R/tools/gabor_stage_probe.py steps > $O/${TAG}_final_gstage.log 2>&1 \
-  && { python $R/tools/gabor_stage_probe.py show $O/prof_gstage; grep -i "stage" $O/${TAG}_final_gstage.log | tail -2; } > $P/${TAG}_gabor_stage_timeline.txt 2>&1
+  && { python $R/tools/gabor_stage_probe.py show $O/prof_gstage; grep "gabor stage inside" $O/${TAG}_final_gstage.log | tail -1; } > $P/${TAG}_gabor_stage_timeline.txt 2>&1
 ls $P | tr '\n' ' '
