@@ -129,3 +129,27 @@ def test_debug_switches_parse_and_reject_unknown_names():
     a, b = _seg(), _seg()
     a.debug.force_collectives = True
     assert not b.debug.force_collectives
+
+
+def test_lds_bank_model_matches_the_deep_bank_kernel_constants():
+    """tools/design/lds_bank_model.py restates the LDS accesses of kmeans_pass_native_kernel against the lane groups the LDS serves
+    (profiles/r5_notes.md). It must model the layout that ships: its row pitches and A-table slot count are the kernel's, every read
+    pattern is conflict-free in the model, and the first round-5 build (--first) reproduces its 624 extra cycles per tile."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "gabor_color_image_segmentation_amd", "csrc", "kmeans.hip")).read()
+    m = re.search(r"NV_P1 = (\d+) \+ (\d+), NV_P2 = (\d+) \+ (\d+), NV_P3 = (\d+);", src)
+    p1, p2 = int(m.group(1)) + int(m.group(2)), int(m.group(3)) + int(m.group(4))
+    nsl = int(re.search(r"constexpr int NV_APAT_SLOTS = (\d+);", src).group(1))
+    model = open(os.path.join(root, "tools", "design", "lds_bank_model.py")).read()
+    assert f"else ({p1}, {p2}, {nsl})" in model, (p1, p2, nsl)
+    tool = os.path.join(root, "tools", "design", "lds_bank_model.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, check=True).stdout
+    rows = {l[:42].strip(): int(l[42:].split()[0]) for l in out.splitlines() if "extra LDS cycles" in l}
+    assert all(v == 0 for k, v in rows.items() if not k.startswith("staging")), rows
+    assert rows["staging  ds_write_b128 / 2 x b64"] <= 30
+    first = subprocess.run([sys.executable, tool, "--first"], capture_output=True, text=True, check=True).stdout
+    assert re.search(r"total\s+624", first), first
