@@ -70,6 +70,18 @@ def _numpy_worker(args):
     return _t.perf_counter() - t0
 
 
+def _numpy_import_only(_):
+    """Warms a pool worker: imports what _numpy_worker imports, so that the pooled figure times segmentation only."""
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard  # noqa: F401
+    from oracle import spec_oracle  # noqa: F401
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:  # pragma: no cover
+        pass
+    return 0
+
+
 def _c_oracle_worker(args):
     """Runs in a spawned process (OpenMP inside): the C restatement of SPEC.md on the WHOLE timed batch, same
     codebook mode, so that every label of the configuration bench.py times can be compared with the GPU result."""
@@ -109,11 +121,26 @@ def cpu_baseline(batch, k, n_iter, mode):
         wall, c_single, ref = pool.apply_async(_c_oracle_worker, [(batch, k, n_iter, mode, cores)]).get(timeout=600)
         log(f"cpu baseline: C oracle {wall:.1f} s; NumPy oracle, one image")
         np_single = pool.apply_async(_numpy_worker, [(0, k, n_iter)]).get(timeout=300)
+    # SURVEY.md §8d (ii), north_star's "reference NumPy/scipy path timed on the node's own host cores (count stated)": the NumPy +
+    # scipy oracle in a process pool over images, one single-threaded worker per usable core, one image of the timed batch each
+    # (per-image codebooks: images are independent units, script.py:22-38); wall clock from the first worker's start to the last
+    # one's end, interpreter start-up excluded
+    n_pool = min(cores, batch)
+    log(f"cpu baseline: NumPy oracle, pool of {n_pool} single-threaded workers, one image each")
+    with ctx.Pool(n_pool) as pool:
+        pool.map(_numpy_import_only, range(n_pool))                 # workers up and modules imported before the clock starts
+        t0 = time.perf_counter()
+        pool.map(_numpy_worker, [(i, k, n_iter) for i in range(n_pool)], chunksize=1)
+        np_pool_wall = time.perf_counter() - t0
     return ref, dict(value=round(batch * H * W / wall / 1e6, 3), unit="Mpix/s", cores=cores, kind="port",
                      seconds=round(wall, 2), host_cpu_count=os.cpu_count(), affinity_cores=affinity,
                      cgroup_cpu_quota=quota,
                      c_single_thread_mpix_s=round(H * W / c_single / 1e6, 4),
                      numpy_single_thread_mpix_s=round(H * W / np_single / 1e6, 4),
+                     numpy_pool_mpix_s=round(n_pool * H * W / np_pool_wall / 1e6, 4), numpy_pool_workers=n_pool,
+                     numpy_pool_note=f"oracle/spec_oracle.segment (NumPy + scipy.ndimage) on {n_pool} images of the timed batch, "
+                                     f"one single-threaded worker process per usable core ({n_pool} of os.cpu_count() = {os.cpu_count()}), "
+                                     f"per-image codebooks, {np_pool_wall:.1f} s wall",
                      sample=f"all {batch} synthetic {W}x{H}x3 images of the timed batch, same bank/k/n_iter, {mode} "
                             f"codebook: C restatement of SPEC.md with OpenMP on {cores} threads (affinity {affinity}, cgroup quota {quota}, "
                             f"os.cpu_count() = {os.cpu_count()}); single-thread figures: one image, run alone")
@@ -304,7 +331,14 @@ def main():
     lv = [(3 * min(2, bank.n_scales - 2 * L) * bank.n_orient, 4 ** L) for L in range(bank.n_levels)]
     feat_b = 2 * sum(d / q for d, q in lv)
     g_bytes = (3 + feat_b) * px                      # u8 RGB in + u16 pyramid features out
-    a_bytes = (feat_b + 4 / args.n_iter) * px        # per Lloyd pass: u16 pyramid features in; the int32 raster label map is stored by the last pass only
+    # Round 6: banks like this one keep the slab SPLIT (include/gcs.h, ABI 18): a pass streams 12 of the 16 bits of every value
+    # and the last 4 only for tiles flagged "some value >= 4096" (6 of 10 016 tiles of this batch's first 16 images:
+    # profiles/r6_notes.md), so the pass's algorithmic bytes are 3/4 of the feature bytes. The 16-bit figure stays beside it.
+    lib = seg.ops.lib
+    split = lib.gcs_feature_pass_bytes(1, H, W, bank.n_scales, bank.n_orient) < 0.8 * lib.gcs_feature_slab_bytes(1, H, W, bank.n_scales, bank.n_orient)
+    pass_b = feat_b * (0.75 if split else 1.0)
+    a_bytes = (pass_b + 4 / args.n_iter) * px        # per Lloyd pass: pyramid features in; the int32 raster label map is stored by the last pass only
+    a_bytes_u16 = (feat_b + 4 / args.n_iter) * px    # the rounds 2-5 definition (every value read at 16 bits)
     g_ops = sum(2 * bank.ksize ** 2 * (4 * d // 3) * 3 * px / q for d, q in lv)   # int8 MACs x2: 2 digits x {re,im} x F_L rows
     kernels = {
         "gabor_mfma_kernel": dict(launches=g_n, launches_per_step=1, avg_ms=round(g_ms, 4), alg_bytes=int(g_bytes),
@@ -316,7 +350,9 @@ def main():
         "kmeans_pass_mfma_kernel": dict(launches=a_n, launches_per_step=args.n_iter, avg_ms=round(a_ms, 4),
                                      alg_bytes=int(a_bytes), unfused_def_bytes=(2 * D + 1) * px,
                                      gbs=round(a_bytes / a_ms / 1e6, 1),
-                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4)),
+                                     hbm_frac=round(a_bytes / a_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                     alg_bytes_u16_def=int(a_bytes_u16),
+                                     hbm_frac_u16_def=round(a_bytes_u16 / a_ms / 1e6 / HBM_PEAK_GBS, 4)),
     }
     if g_ms >= a_ms * args.n_iter:    # dominant = larger share of the step (`launches` = launches bracketed by events)
         kg = kernels["gabor_mfma_kernel"]
@@ -329,9 +365,24 @@ def main():
         ka = kernels["kmeans_pass_mfma_kernel"]
         roofline = dict(kernel="kmeans_pass_mfma_kernel", bound="hbm", achieved=ka["gbs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ka["hbm_frac"], traffic=None,
-                        alg_bytes_def="pyramid-resident: 2*sum_L D_L/4^L B/px read by every pass + the label map stored by the "
-                                      "last one (4 B/px int32 / n_iter) = 90.4 B/px per launch for the 4x6 bank, n_iter 10 "
-                                      "(SURVEY.md §8d's un-fused 2D+1 = 145 B/px describes work this pass no longer does)")
+                        alg_bytes_def=("split slab (ABI 18): 1.5*sum_L D_L/4^L B/px (12 of the 16 bits of every value; the last 4 only "
+                                       "for flagged tiles, ~0 here) + the label map stored by the last pass (4 B/px int32 / n_iter) = "
+                                       "67.9 B/px per launch for the 4x6 bank, n_iter 10; frac_u16_def prices the same launch at the "
+                                       "rounds 2-5 definition (90.4 B/px: bytes this pass no longer reads)" if split else
+                                       "pyramid-resident: 2*sum_L D_L/4^L B/px read by every pass + the label map stored by the "
+                                       "last one (4 B/px int32 / n_iter)"),
+                        frac_u16_def=ka["hbm_frac_u16_def"])
+        # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this command (tools/profile_round.sh):
+        # the dominant kernel's average over ALL its launches, spin-up included
+        try:
+            import csv
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "kernel_stats_latest.csv"))))
+            row = max((r for r in rows if "kmeans_pass_mfma_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+            roofline["frac_rocprof"] = round(a_bytes / (float(row["AverageNs"]) * 1e-9) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["rocprof_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+            roofline["rocprof_source"] = "profiles/kernel_stats_latest.csv (%s launches of %s)" % (row["Calls"], row["Name"].split("(")[0])
+        except Exception:
+            pass
 
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this same
     # command (tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no profile matches.
@@ -507,7 +558,9 @@ def main():
                     config=dict(workload=f"batch {B}/GPU synthetic {W}x{H}x3 uint8 (seed 0), 4-scale x "
                                          f"6-orientation Gabor bank ksize {bank.ksize} on a {bank.n_levels}-level octave pyramid, k={args.k}, "
                                          f"n_iter={args.n_iter}",
-                                codebook=args.mode, global_batch=world * B, features="uint16 Q7, level L at 1/4^L resolution",
+                                codebook=args.mode, global_batch=world * B,
+                                features="uint16 Q7, level L at 1/4^L resolution" + (
+                                    "; slab split into low byte / bits 8-11 / bits 12-15, the last read per flagged tile only" if split else ""),
                                 parallelism=f"dp{world} (images sharded, int64 centroid all-reduce)"
                                 if args.mode == "global" else f"dp{world} (independent images)"),
                     roofline=roofline, cpu_baseline=cpu, kernels=kernels,
@@ -515,10 +568,11 @@ def main():
                     device_cu_count=int(seg.ops.lib.gcs_device_cu_count()), multi_gpu=multi,
                     # whole job against the HBM roof: Gabor + n_iter passes, pyramid-resident bytes per pixel (and the
                     # un-fused uint16 definition of SURVEY.md §8d beside it), per GPU
-                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * feat_b + 4, 1),
-                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * feat_b + 4) * px * args.steps / dt / 1e9, 1),
-                                    hbm_frac=round(((3 + feat_b) + args.n_iter * feat_b + 4) * px * args.steps / dt / 1e9
+                    end_to_end=dict(alg_bytes_per_px=round((3 + feat_b) + args.n_iter * pass_b + 4, 1),
+                                    gbs_per_gpu=round(((3 + feat_b) + args.n_iter * pass_b + 4) * px * args.steps / dt / 1e9, 1),
+                                    hbm_frac=round(((3 + feat_b) + args.n_iter * pass_b + 4) * px * args.steps / dt / 1e9
                                                    / HBM_PEAK_GBS, 4),
+                                    alg_bytes_per_px_u16_def=round((3 + feat_b) + args.n_iter * feat_b + 4, 1),
                                     ),
                     **extra)
         print(json.dumps(line))

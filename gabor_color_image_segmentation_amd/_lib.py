@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libgcs.so")  # override: A/B builds
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 K_MAX = 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -25,6 +25,7 @@ SIGNATURES = {
     "gcs_bank_bias_count": (_sz, [_i, _i]),
     "gcs_bank_pack": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "gcs_feature_slab_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "gcs_feature_pass_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gcs_label_slab_bytes": (_sz, [_i, _i, _i]),
     "gcs_kmeans_parts_per_image": (_sz, [_i, _i, _i]),
     "gcs_kmeans_partial_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -70,7 +70,12 @@ extern "C" size_t gcs_bank_bias_count(int n_scales, int n_orient) {
 extern "C" size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient) {
     GcsLayout lo;
     if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo)) return 0;
-    return (size_t)B * lo.ntiles * lo.tile_bytes;
+    return (size_t)B * (size_t)lo.img_bytes;      // per image: ntiles * tile_bytes feature bytes (+ the flag words of a split slab)
+}
+extern "C" size_t gcs_feature_pass_bytes(int B, int H, int W, int n_scales, int n_orient) {
+    GcsLayout lo;
+    if (B <= 0 || !gcs_make_layout(H, W, n_scales, n_orient, &lo)) return 0;
+    return (size_t)B * lo.ntiles * (lo.split ? (size_t)lo.S + lo.S / 2 : (size_t)lo.tile_bytes);
 }
 extern "C" size_t gcs_label_slab_bytes(int B, int H, int W) {            // uint8 raster map [B][H][W], padded to 16 bytes
     if (B <= 0 || H <= 0 || W <= 0) return 0;

@@ -52,6 +52,21 @@ static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles o
 //                 so the level-1 replication the kernels do (slot (iy, ix) -> parent slot (iy >> 1, ix >> 1)) holds
 //                 unchanged, and 481 x 321 takes 2 426 blocks (2 400 + 11 + 15) instead of 2 501. Deeper banks keep
 //                 main blocks only (a strip block's 8 level-2 parents do not fit a block's 2x2 level-2 slots).
+//
+// SPLIT slab (round 6: banks of at most two levels with D <= 79, i.e. every 4x6-style bank). SPEC.md §3 allows g <= 46 163, but
+// values of 4096 and more are 5.6e-5 of what BSD500 produces and 2e-7 of the synthetic bench batch (tools/design/
+// narrow_slab_study.py, profiles/r6_notes.md), while every Lloyd pass streamed 16 bits for each. A value is therefore stored
+// as three pieces in three planar arrays per image, all in the tile / plane / slot order above (a tile = S slots, level L
+// starting at slot sl0[L]):
+//     LO   [ntiles][S]      the low byte, XOR 0x80 (the signed low MFMA digit)
+//     MID  [ntiles][S / 2]  bits 8..11, two slots per byte
+//     TOP  [ntiles][S / 2]  bits 12..15, two slots per byte
+//     FLAG [ntiles][4]      byte L != 0: some TOP nibble of the tile's level-L planes is non-zero
+// A pass reads LO and MID of every tile (12 bits per value: 67.5 instead of 90 B/px for the default bank) and the TOP run of the
+// tiles whose flag word is non-zero - exact for any data, and never more bytes than the wide slab. Nibble pairing inside a group of
+// g = max(2, 8 >> L) consecutive slots (a block row on level 0, a parent row on level 1): byte i of the group (i < g / 2) holds
+// slot i in bits 0..3 and slot i + g / 2 in bits 4..7, so that `x & 0x0f0f0f0f` and `(x >> 4) & 0x0f0f0f0f` are the high bytes of
+// the group's first and second half in slot order (the passes' unpack) and a lane of the Gabor kernel owns whole bytes.
 constexpr int GCS_LEVELS_MAX = 4;
 constexpr int KP_TP = 256;            // pixels per tile = threads per k-means workgroup
 constexpr int GCS_NO_STRIP = 1 << 29; // Wm / Hm of a layout without that strip: no coordinate reaches it
@@ -69,8 +84,18 @@ struct GcsLayout {
     int row0[GCS_LEVELS_MAX];         // first physical plane of level L
     int off[GCS_LEVELS_MAX];          // byte offset of level L inside a tile
     int HL[GCS_LEVELS_MAX], WL[GCS_LEVELS_MAX];   // level image size
-    int tile_bytes;
+    int tile_bytes;                   // feature bytes of one tile (wide: one contiguous run; split: 2 S, in three arrays)
+    // split slab (see above); wide slabs: split == 0, img_bytes == ntiles * tile_bytes
+    int split;
+    int S;                            // slots per tile
+    int sl0[GCS_LEVELS_MAX];          // first slot of level L inside a tile
+    unsigned mid_off, top_off, flag_off;   // byte offsets of the MID / TOP / FLAG arrays inside one image's slab
+    long long img_bytes;              // bytes of one image's slab (gcs_feature_slab_bytes(B) = B * img_bytes)
 };
+
+// Which banks take the split slab: those whose Lloyd pass is kmeans_pass_mfma_kernel's narrow bucket and whose Gabor stores are
+// the level-0 / level-1 paths.
+static inline bool gcs_split_bank(int n_levels, int D) { return n_levels <= 2 && D < 80; }
 
 // Tiles per image when no edge strip is packed: an upper bound of every bank's tile count for the shape (sizes that
 // must not depend on the bank: partial-sum rows per image).
@@ -120,6 +145,23 @@ static inline bool gcs_make_layout(int H, int W, int n_scales, int n_orient, Gcs
         w = (w + 1) / 2;
     }
     lo->tile_bytes = off;
+    lo->img_bytes = (long long)lo->ntiles * lo->tile_bytes;
+    if (gcs_split_bank(lo->n_levels, lo->D)) {
+        lo->split = 1;
+        int sl = 0;
+        for (int L = 0; L < lo->n_levels; ++L) {
+            lo->sl0[L] = sl;
+            sl += round_up(lo->DL[L] * (KP_TP >> (2 * L)), 32);
+        }
+        lo->S = sl;
+        lo->tile_bytes = 2 * sl;
+        const long long lo_bytes = (long long)lo->ntiles * sl;
+        if (2 * lo_bytes + 4LL * lo->ntiles + 256 > 0xffffffffLL) return false;
+        lo->mid_off = (unsigned)lo_bytes;
+        lo->top_off = (unsigned)(lo_bytes + lo_bytes / 2);
+        lo->flag_off = (unsigned)(2 * lo_bytes);
+        lo->img_bytes = 2 * lo_bytes + round_up(4 * lo->ntiles, 256);
+    }
     return true;
 }
 
@@ -175,16 +217,44 @@ __host__ __device__ __forceinline__ int gcs_plane_of_logical(const GcsLayout &lo
     return lo.row0[L] + c * lo.FL[L] + (f - 2 * L * lo.n_orient);
 }
 
-// Byte offset (from the slab base) of the value of physical plane r at FULL-resolution pixel (y, x) of image b:
-// the level-L parent slot (iy >> L, ix >> L) inside the pixel's block.
+// WIDE slab: byte offset (from the slab base) of the value of physical plane r at FULL-resolution pixel (y, x) of image b:
+// the level-L parent slot (iy >> L, ix >> L) inside the pixel's block. (Either format: gcs_slab_value.)
 __device__ __forceinline__ size_t gcs_slab_offset(const GcsLayout &lo, int b, int r, int y, int x) {
     const int L = gcs_level_of_plane(lo, r);
     int blk, iy, ix;
     gcs_locate(lo, y, x, blk, iy, ix);
     const int side = 8 >> L;                                          // sub-block side at level L
     const int npl = KP_TP >> (2 * L);                                 // pixels per plane of a tile at level L
-    return ((size_t)b * lo.ntiles + (blk >> 2)) * lo.tile_bytes + lo.off[L] +
+    return (size_t)b * lo.img_bytes + (size_t)(blk >> 2) * lo.tile_bytes + lo.off[L] +
            ((size_t)(r - lo.row0[L]) * npl + (blk & 3) * side * side + (iy >> L) * side + (ix >> L)) * 2;
+}
+
+// ---- split slab: slot index (inside the image: tile * S + slot in tile) of physical plane r at full-resolution pixel (y, x)
+__host__ __device__ __forceinline__ unsigned gcs_split_slot(const GcsLayout &lo, int r, int y, int x) {
+    const int L = gcs_level_of_plane(lo, r);
+    int blk, iy, ix;
+    gcs_locate(lo, y, x, blk, iy, ix);
+    const int side = 8 >> L, npl = KP_TP >> (2 * L);
+    return (unsigned)(blk >> 2) * (unsigned)lo.S + (unsigned)(lo.sl0[L] + (r - lo.row0[L]) * npl + (blk & 3) * side * side +
+                                                              (iy >> L) * side + (ix >> L));
+}
+// byte (relative to the MID / TOP array) and bit shift of a slot's nibble: group of g = max(2, 8 >> L) slots, see above
+__host__ __device__ __forceinline__ void gcs_split_nibble(int L, unsigned slot, unsigned &byte, int &shift) {
+    const unsigned g = (8u >> L) > 2u ? (8u >> L) : 2u, h = g >> 1;
+    const unsigned gi = slot % g, second = gi >= h ? 1u : 0u;
+    byte = (slot / g) * h + gi - second * h;
+    shift = 4 * (int)second;
+}
+// The value (SPEC.md §3: plain uint16, no offset) of physical plane r at full-resolution pixel (y, x) of image b, either format.
+__device__ __forceinline__ unsigned gcs_slab_value(const unsigned char *feats, const GcsLayout &lo, int b, int r, int y, int x) {
+    if (!lo.split) return *reinterpret_cast<const uint16_t *>(feats + gcs_slab_offset(lo, b, r, y, x)) ^ 0x8080u;
+    const unsigned char *img = feats + (size_t)b * lo.img_bytes;
+    const unsigned slot = gcs_split_slot(lo, r, y, x);
+    unsigned nb;
+    int sh;
+    gcs_split_nibble(gcs_level_of_plane(lo, r), slot, nb, sh);
+    const unsigned lo8 = img[slot] ^ 0x80u, mid = (img[lo.mid_off + nb] >> sh) & 15u, top = (img[lo.top_off + nb] >> sh) & 15u;
+    return lo8 | (mid << 8) | (top << 12);
 }
 
 // Partial sums of one Lloyd pass: [set][chunk of 16 elements][row][16] uint64, one row per k-means workgroup (sets = images

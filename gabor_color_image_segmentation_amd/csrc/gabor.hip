@@ -127,6 +127,24 @@ __device__ __forceinline__ void plane_deinterleave4(unsigned d0, unsigned d1, un
     b = __builtin_amdgcn_perm(b23, b01, 0x07060100u) ^ 0x80808080u;
 }
 
+// Split slab (csrc/common.h): the pre-pass of level L clears that level's byte of every tile's flag word in front of the level's
+// bank launches, which set it where a top nibble is non-zero (zmask: bit L = clear byte L; level 0 also clears the bytes of the
+// levels the bank does not have). base == NULL: wide slab, nothing to do.
+struct GaborFlagZero {
+    unsigned char *base;      // the slab
+    long long img_bytes;
+    unsigned flag_off;
+    int ntiles, zmask;
+};
+__device__ __forceinline__ void gabor_zero_flags(const GaborFlagZero &z, int b, int first, int stride) {
+    if (!z.base) return;
+    unsigned char *f = z.base + (size_t)b * z.img_bytes + z.flag_off;
+    for (int t = first; t < z.ntiles; t += stride)
+#pragma unroll
+        for (int L = 0; L < GCS_LEVELS_MAX; ++L)
+            if (z.zmask >> L & 1) f[4 * t + L] = 0;
+}
+
 // (the body: workgroup bx of gdx of image b, so that a small call can run it beside the level-1 pre-pass in ONE launch)
 __device__ __forceinline__ void gabor_plane_body(int bx, int gdx, int b, const uint8_t *__restrict__ src, int Hs, int Ws, int HL,
                                                  int WL, int Hp, int Wp, int8_t *__restrict__ planes) {
@@ -191,8 +209,9 @@ __device__ __forceinline__ void gabor_plane_body(int bx, int gdx, int b, const u
 template <int MODE>
 __global__ __launch_bounds__(256) void gabor_plane_kernel(const uint8_t *__restrict__ src, int Hs, int Ws, int HL, int WL,
                                                           int Hp, int Wp, int8_t *__restrict__ planes,
-                                                          uint8_t *__restrict__ img_out) {
+                                                          uint8_t *__restrict__ img_out, GaborFlagZero fz) {
     static_assert(MODE == 0, "levels >= 1 use gabor_down_kernel");
+    gabor_zero_flags(fz, (int)blockIdx.y, (int)blockIdx.x * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
     gabor_plane_body((int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, src, Hs, Ws, HL, WL, Hp, Wp, planes);
 }
 
@@ -261,8 +280,9 @@ __device__ __forceinline__ void gabor_down_body(int r, int b, unsigned char *s_r
 template <bool SRC_RGB>
 __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restrict__ src, size_t src_bytes, int Hs, int Ws,
                                                          int HL, int WL, int Hp, int Wp, int8_t *__restrict__ planes,
-                                                         uint8_t *__restrict__ img_out) {
+                                                         uint8_t *__restrict__ img_out, GaborFlagZero fz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_rows[];
+    gabor_zero_flags(fz, (int)blockIdx.y, (int)blockIdx.x * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
     gabor_down_body<SRC_RGB>((int)blockIdx.x, (int)blockIdx.y, s_rows, src, src_bytes, Hs, Ws, HL, WL, Hp, Wp, planes, img_out);
 }
 // The level-0 and level-1 pre-passes of a two-level bank in ONE launch (small calls: each is a 5 - 7 us launch of its own in
@@ -270,8 +290,10 @@ __global__ __launch_bounds__(256) void gabor_down_kernel(const uint8_t *__restri
 // padded level-1 row each.
 __global__ __launch_bounds__(256) void gabor_pre01_kernel(const uint8_t *__restrict__ src, size_t src_bytes, int H, int W, int n0,
                                                           int H0, int W0, int Hp0, int Wp0, int8_t *__restrict__ planes0,
-                                                          int H1, int W1, int Hp1, int Wp1, int8_t *__restrict__ planes1) {
+                                                          int H1, int W1, int Hp1, int Wp1, int8_t *__restrict__ planes1,
+                                                          GaborFlagZero fz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_rows[];
+    gabor_zero_flags(fz, (int)blockIdx.y, (int)blockIdx.x * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
     if ((int)blockIdx.x < n0) gabor_plane_body((int)blockIdx.x, n0, (int)blockIdx.y, src, H, W, H0, W0, Hp0, Wp0, planes0);
     else gabor_down_body<true>((int)blockIdx.x - n0, (int)blockIdx.y, s_rows, src, src_bytes, H, W, H1, W1, Hp1, Wp1, planes1, nullptr);
 }
@@ -307,6 +329,10 @@ struct GaborLevels {
 struct GaborSlab {
     int bx_n;                // main blocks per block row
     int ntiles, tile_bytes;
+    long long img_bytes;     // bytes of one image's slab
+    // split slab (csrc/common.h; GaborLevel::offL is then the level's first SLOT of a tile)
+    int S;
+    unsigned mid_off, top_off, flag_off;
 };
 
 // The bank of one level as an im2col GEMM on v_mfma_i32_32x32x32_i8 (round 3 layout).
@@ -334,7 +360,9 @@ struct GaborSlab {
 constexpr int G_COPY = 3 * G_LROWS * G_LPITCH;      // bytes of one copy of a tile (three channels)
 
 
-template <int MT, int GQ, int KS, int LVL, bool FAST>
+// SPLIT = the split slab (csrc/common.h: low bytes, MID nibbles and TOP nibbles in three planar arrays + a flag per tile and level);
+// banks of at most two levels: store paths for levels 0 and 1 only, whatever LVL.
+template <int MT, int GQ, int KS, int LVL, bool FAST, bool SPLIT = false>
 __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
     GaborLevels G, int FLv, int fbase0, int shift, unsigned char *__restrict__ feats, int total_tiles, GaborSlab S) {
     // blockIdx.y = row-tile GROUP of the launch: group q works on filters fbase0 + 4 MT q .. of every tile of the list (a small call -
@@ -519,11 +547,16 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
         };
         // the two pixels of a pair -> one dword of the slab: offset-binary (x ^ 0x8080: both bytes are then signed MFMA digits
         // for the k-means pass, which stages them untouched), the odd pixel in the high half
+        // (split slab: the pair as (lo_a, lo_b, hi_a, hi_b), no offset yet - store_block separates the bytes of four pairs)
         auto epi_pack = [&](unsigned q0, unsigned q1, int mt, int fp, int pp) {
             unsigned &o = outp[mt][fp][pp];
-            if constexpr (FAST) o = __builtin_amdgcn_perm(q1, q0, 0x05040100u);   // low halves: the 0x4B000000 bias drops out
-            else o = __umul24(q1, k65536) + q0;
-            o ^= 0x80808080u;
+            if constexpr (SPLIT) {
+                o = __builtin_amdgcn_perm(q1, q0, 0x05010400u);
+            } else {
+                if constexpr (FAST) o = __builtin_amdgcn_perm(q1, q0, 0x05040100u);   // low halves: the 0x4B000000 bias drops out
+                else o = __umul24(q1, k65536) + q0;
+                o ^= 0x80808080u;
+            }
             asm volatile("" : "+v"(o));     // materialise now: hipcc otherwise sinks the packing into the store branches
         };
         // Slice `slot` (= the K-step the chain in flight is at) of the epilogue of finished chain (mt, pp): slots 1..4 one
@@ -546,13 +579,78 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             // compile-time geometry for single-level launches
             const int Lc = LVL >= 0 ? LVL : L, ssh = LVL >= 0 ? 3 - LVL : side_sh, nplc = LVL >= 0 ? (KP_TP >> (2 * (LVL >= 0 ? LVL : 0))) : npl;
             const int oy = y0 + st_trow, ox = x0 + 8 * li;
+            if constexpr (SPLIT) {
+              if (oy < HL && ox < pitchL) {
+                // Split slab: the lane's 8 pixels are 8 consecutive SLOTS of one block row (level 0) or 4 + 4 slots of one parent
+                // row of two neighbouring blocks (level 1). Per filter: the low bytes (XOR 0x80) go to LO at the slot index, the
+                // nibbles 8..11 / 12..15 of slots i and i + g / 2 of the group share byte i of MID / TOP at half the slot index.
+                const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
+                const int bx0 = ox >> ssh;
+                unsigned char *img = feats + (size_t)b * S.img_bytes;
+                const unsigned pl0 = (unsigned)(offL + (st_c * FLv + fbase) * nplc);          // first slot of the launch's first plane of channel st_c
+                unsigned char *lo_base = img + pl0, *mid_base = img + S.mid_off + (pl0 >> 1), *top_base = img + S.top_off + (pl0 >> 1);
+                const unsigned row_slot = (unsigned)((iy << ssh) + h * nplc);
+                auto lane_slot = [&](int p) -> unsigned {
+                    const int blk = by * S.bx_n + bx0 + p;
+                    return (unsigned)(blk >> 2) * (unsigned)S.S + (unsigned)((blk & 3) << (2 * ssh)) + row_slot;
+                };
+                auto planes = [&](auto &&put) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int fp = 0; fp < 2; ++fp) {
+                            if (mt == MT - 1 && fp >= GQ) continue;
+                            const bool last = mt == MT - 1 && fp == GQ - 1;
+                            if (last && fbase + 4 * mt + 2 * fp + h >= FLv) continue;
+                            put((unsigned)((4 * mt + 2 * fp) * nplc), outp[mt][fp][0], outp[mt][fp][1], outp[mt][fp][2], outp[mt][fp][3]);
+                        }
+                };
+                if (Lc == 0) {
+                    const unsigned s0 = lane_slot(0), n0 = s0 >> 1;
+                    unsigned any = 0;
+                    planes([&](unsigned po, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        const unsigned l0 = __builtin_amdgcn_perm(w1, w0, 0x05040100u) ^ 0x80808080u;
+                        const unsigned l1 = __builtin_amdgcn_perm(w3, w2, 0x05040100u) ^ 0x80808080u;
+                        const unsigned h0 = __builtin_amdgcn_perm(w1, w0, 0x07060302u);          // high bytes of pixels 0..3
+                        const unsigned h1 = __builtin_amdgcn_perm(w3, w2, 0x07060302u);          // ... of pixels 4..7
+                        const unsigned mid = (h0 & 0x0f0f0f0fu) | ((h1 << 4) & 0xf0f0f0f0u);
+                        const unsigned top = ((h0 >> 4) & 0x0f0f0f0fu) | (h1 & 0xf0f0f0f0u);
+                        __builtin_nontemporal_store(v2i{(int)l0, (int)l1}, reinterpret_cast<v2i *>(lo_base + po + s0));
+                        __builtin_nontemporal_store(mid, reinterpret_cast<unsigned *>(mid_base + (po >> 1) + n0));
+                        __builtin_nontemporal_store(top, reinterpret_cast<unsigned *>(top_base + (po >> 1) + n0));
+                        any |= top;
+                    });
+                    if (any) img[S.flag_off + 4u * (unsigned)((by * S.bx_n + bx0) >> 2)] = 1;
+                } else {
+                    const unsigned s0 = lane_slot(0), s1 = lane_slot(1);
+                    const bool has1 = bx0 + 1 < S.bx_n;
+                    unsigned any0 = 0, any1 = 0;
+                    auto half = [&](unsigned po, unsigned wa, unsigned wb, unsigned sl, unsigned &any) {
+                        const unsigned l = __builtin_amdgcn_perm(wb, wa, 0x05040100u) ^ 0x80808080u;
+                        const unsigned hh = __builtin_amdgcn_perm(wb, wa, 0x07060302u);          // high bytes of the four pixels
+                        const unsigned mid = (hh & 0x0f0fu) | ((hh >> 12) & 0xf0f0u);
+                        const unsigned top = ((hh >> 4) & 0x0f0fu) | ((hh >> 16) & 0xf0f0u);
+                        __builtin_nontemporal_store(l, reinterpret_cast<unsigned *>(lo_base + po + sl));
+                        *reinterpret_cast<uint16_t *>(mid_base + (po >> 1) + (sl >> 1)) = (uint16_t)mid;
+                        *reinterpret_cast<uint16_t *>(top_base + (po >> 1) + (sl >> 1)) = (uint16_t)top;
+                        any |= top;
+                    };
+                    planes([&](unsigned po, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                        half(po, w0, w1, s0, any0);
+                        if (has1) half(po, w2, w3, s1, any1);
+                    });
+                    if (any0) img[S.flag_off + 4u * (unsigned)((by * S.bx_n + bx0) >> 2) + 1u] = 1;
+                    if (any1) img[S.flag_off + 4u * (unsigned)((by * S.bx_n + bx0 + 1) >> 2) + 1u] = 1;
+                }
+              }
+            } else
             if (oy < HL && ox < pitchL) {
                 const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
                 const int bx0 = ox >> ssh;
                 // Address = uniform part (image, level, channel, filter pair: SGPRs, scalar ALU) + one 32-bit lane offset per
                 // target block (tile of the block, block inside the tile, row inside the block, filter parity h), so that a
                 // store costs no vector address arithmetic (global_store with an SGPR base).
-                unsigned char *ubase = feats + (size_t)b * S.ntiles * S.tile_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
+                unsigned char *ubase = feats + (size_t)b * S.img_bytes + offL + (size_t)(st_c * FLv + fbase) * nplc * 2;
                 const unsigned row_off = (unsigned)(((iy << ssh) + h * nplc) * 2);
                 auto lane_off = [&](int p) -> unsigned {           // block bx0 + p, this lane's row inside it
                     const int blk = by * S.bx_n + bx0 + p;
@@ -723,9 +821,27 @@ __global__ __launch_bounds__(256) void gabor_strip_kernel(StripArgs A, GcsLayout
     // Where the pair's magnitudes go: the slot of pixel (y, x) in the channel's first plane of this level; filter fl sits
     // fl planes further (same tile, same slot), the pair's second pixel in the next slot (x is even: slots ix, ix + 1 of a
     // main or strip block; level-1 parents q, q + 1 of one row of four): one 4-byte store per filter
-    const size_t base = gcs_slab_offset(lo, b, v.row0 + c * v.FL, (ok ? y : 0) << v.L, (ok ? x : 0) << v.L);
+    const size_t base = lo.split ? 0 : gcs_slab_offset(lo, b, v.row0 + c * v.FL, (ok ? y : 0) << v.L, (ok ? x : 0) << v.L);
     const int plane_bytes = (KP_TP >> (2 * v.L)) * 2;
     const bool both = x + 1 < xlim;
+    // split slab: the slot of the pair's first pixel in the channel's first plane of this level (filter fl: fl planes further),
+    // its nibble byte, whether the lane owns TWO adjacent slots (everything but the one-column right strip of level 1, whose
+    // neighbouring slot is the next row's), how far the lane with the other half of the nibble group is, and who stores the bytes
+    unsigned slot0 = 0, nbyte0 = 0;
+    bool pairs = true, writer = false;
+    int pdist = 1;
+    if (lo.split) {
+        slot0 = gcs_split_slot(lo, v.row0 + c * v.FL, (ok ? y : 0) << v.L, (ok ? x : 0) << v.L);
+        int sh;
+        gcs_split_nibble(v.L, slot0, nbyte0, sh);
+        writer = sh == 0;
+        const bool column = seg < v.nseg_col;
+        pairs = !(column && v.L == 1);
+        // lanes per half group: column strip, level 0: a block row holds 4 pixel rows (8 slots = 4 parents x 2 columns): 4 / 2 = 2
+        // row pairs = 4 lanes; level 1: 4 parents = 4 lanes, half = 2. Row strip, level 0: 8 slots = 4 lanes, half = 2; level 1: 4
+        // slots = 2 lanes, half = 1.
+        pdist = column ? (v.L == 0 ? 4 : 2) : (v.L == 0 ? 2 : 1);
+    }
     const v4i *ap = reinterpret_cast<const v4i *>(v.apack) + lane;
     v4i a_cur[KS], a_nxt[KS];
 #pragma unroll
@@ -752,6 +868,34 @@ __global__ __launch_bounds__(256) void gabor_strip_kernel(StripArgs A, GcsLayout
                 const int a_re = v_re >> shift, a_im = v_im >> shift;
                 mag[sx] = isqrt31((unsigned)__mul24(a_re, a_re) + (unsigned)__mul24(a_im, a_im));
             }
+            if (lo.split) {
+                // Split slab: a slot's MID / TOP nibble shares its byte with the slot half a group further on (csrc/common.h), which
+                // another lane of this wave computes: the lane `pdist` further on in the 32-lane half. Every lane hands its pair to
+                // the shuffle (absent pixels as 0); the lanes whose slots are the FIRST half of their group (`writer`) store whole bytes.
+                const unsigned pk = (ok && fl < v.FL) ? (mag[0] | (both ? mag[1] << 16 : 0u)) : 0u;
+                const unsigned pt = (unsigned)__shfl_down((int)pk, pdist, 32);          // (every lane takes part)
+                const unsigned pr = n + pdist < 32 ? pt : 0u;
+                if (ok && fl < v.FL) {
+                    unsigned char *img = feats + (size_t)b * lo.img_bytes;
+                    const unsigned sl = slot0 + (unsigned)fl * (unsigned)(KP_TP >> (2 * v.L));
+                    if (pairs) *reinterpret_cast<uint16_t *>(img + sl) = (uint16_t)(((pk & 0xffu) | ((pk >> 8) & 0xff00u)) ^ 0x8080u);
+                    else img[sl] = (unsigned char)((pk & 0xffu) ^ 0x80u);
+                    if (writer) {
+                        // own high bytes (a, b) and the partner's (c, d): byte 0 = a | c << 4, byte 1 = b | d << 4 (nibble-wise)
+                        const unsigned own = ((pk >> 8) & 0xffu) | ((pk >> 16) & 0xff00u), oth = ((pr >> 8) & 0xffu) | ((pr >> 16) & 0xff00u);
+                        const unsigned mid = (own & 0x0f0fu) | ((oth << 4) & 0xf0f0u), top = ((own >> 4) & 0x0f0fu) | (oth & 0xf0f0u);
+                        const unsigned nb = nbyte0 + (unsigned)fl * (unsigned)(KP_TP >> (2 * v.L + 1));
+                        if (pairs) {
+                            *reinterpret_cast<uint16_t *>(img + lo.mid_off + nb) = (uint16_t)mid;
+                            *reinterpret_cast<uint16_t *>(img + lo.top_off + nb) = (uint16_t)top;
+                        } else {
+                            img[lo.mid_off + nb] = (unsigned char)mid;
+                            img[lo.top_off + nb] = (unsigned char)top;
+                        }
+                        if (top & (pairs ? 0xffffu : 0xffu)) img[lo.flag_off + 4u * (slot0 / (unsigned)lo.S) + (unsigned)v.L] = 1;
+                    }
+                }
+            } else
             if (ok && fl < v.FL) {
                 unsigned char *dst = feats + base + (size_t)fl * plane_bytes;
                 if (both) *reinterpret_cast<unsigned *>(dst) = (mag[0] | (mag[1] << 16)) ^ 0x80808080u;
@@ -821,6 +965,17 @@ static GaborSide *gabor_side() {                     // call with g_side_mu held
     return g.s ? &g : nullptr;
 }
 
+// One launch of the bank kernel, for either slab format.
+template <int MT, int GQ, int KS, int LV, bool FA>
+static void gabor_launch(bool split, dim3 grid, dim3 block, hipStream_t st, const GaborLevels &G, int FLg, int f0, int shift,
+                         unsigned char *feats, int total_tiles, const GaborSlab &slab) {
+    if (split) {
+        hipLaunchKernelGGL((gabor_mfma_kernel<MT, GQ, KS, LV, FA, true>), grid, block, 0, st, G, FLg, f0, shift, feats, total_tiles, slab);
+        return;
+    }
+    hipLaunchKernelGGL((gabor_mfma_kernel<MT, GQ, KS, LV, FA, false>), grid, block, 0, st, G, FLg, f0, shift, feats, total_tiles, slab);
+}
+
 extern "C" size_t gcs_gabor_workspace_bytes(int B, int H, int W, int n_scales) {
     if (B <= 0 || H <= 0 || W <= 0 || n_scales < 1 || n_scales > GCS_SCALES_MAX) return 0;
     return gabor_ws(B, H, W, (n_scales + 1) / 2).total;
@@ -840,7 +995,7 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     GcsLayout lo;
     if (!gcs_make_layout(H, W, n_scales, n_orient, &lo))
         return gcs_fail(GCS_EINVAL, "gcs_gabor_features: need 1 <= n_scales <= 8, n_orient >= 1");
-    if ((long long)B * lo.ntiles * lo.tile_bytes > 0x7fffffffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: slab too large");
+    if ((long long)B * lo.img_bytes > 0x7fffffffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: slab too large");
     if ((long long)lo.ntiles * lo.tile_bytes > 0xffffffffLL)   // the kernel addresses one image's slab with 32-bit lane offsets
         return gcs_fail(GCS_EINVAL, "gcs_gabor_features: one image's feature slab must stay below 4 GiB");
     const GaborWs ws = gabor_ws(B, H, W, lo.n_levels);
@@ -899,6 +1054,13 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     long long tiles_all = 0;
     for (int L = 0; L < lo.n_levels; ++L) tiles_all += (long long)B * ((half_tiles(L) + 1) / 2);
     const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
+    // split slab: which flag bytes the pre-pass of level L clears (csrc/common.h; level 0 also those of absent levels)
+    auto flag_zero = [&](int zmask) {
+        GaborFlagZero z{};
+        if (lo.split) z = GaborFlagZero{reinterpret_cast<unsigned char *>(feats), lo.img_bytes, lo.flag_off, lo.ntiles, zmask};
+        return z;
+    };
+    const int zmask0 = 1 | (0xf & ~((1 << lo.n_levels) - 1));
     // ---- pre-passes: the padded planes of every level (level L >= 2 reads level L-1's compact image)
     for (int L = 0; L < lo.n_levels; ++L) {
         if (fuse_small && !forked) {                           // a small call: both pre-passes of the two-level bank in one launch
@@ -907,7 +1069,8 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
             const size_t lds = 2 * (size_t)((W * 3 + 6) & ~3);
             hipLaunchKernelGGL(gabor_pre01_kernel, dim3(n0 + ws.Hp[1], B), block, lds, stream, img, (size_t)B * H * W * 3, H, W, n0,
                                ws.HL[0], ws.WL[0], ws.Hp[0], ws.Wp[0], reinterpret_cast<int8_t *>(wsb + ws.plane_off[0]),
-                               ws.HL[1], ws.WL[1], ws.Hp[1], ws.Wp[1], reinterpret_cast<int8_t *>(wsb + ws.plane_off[1]));
+                               ws.HL[1], ws.WL[1], ws.Hp[1], ws.Wp[1], reinterpret_cast<int8_t *>(wsb + ws.plane_off[1]),
+                               flag_zero(zmask0 | 2));
             GCS_GABOR_CHECK("gcs_gabor_features(pad)");
             continue;
         }
@@ -919,17 +1082,17 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
         uint8_t *img_out = (L >= 1 && L + 1 < lo.n_levels) ? wsb + ws.img_off[L] : nullptr;
         if (L == 0)
             hipLaunchKernelGGL((gabor_plane_kernel<0>), pgrid, block, 0, GCS_STREAM_OF(L), img, H, W, HL, WL, Hp, Wp, planes,
-                               (uint8_t *)nullptr);
+                               (uint8_t *)nullptr, flag_zero(zmask0));
         else if (L == 1) {
             const size_t lds = 2 * (size_t)((W * 3 + 6) & ~3);
             hipLaunchKernelGGL((gabor_down_kernel<true>), dim3(Hp, B), block, lds, GCS_STREAM_OF(L), img, (size_t)B * H * W * 3, H, W,
-                               HL, WL, Hp, Wp, planes, img_out);
+                               HL, WL, Hp, Wp, planes, img_out, flag_zero(2));
         } else {
             const int Hs = ws.HL[L - 1], Ws = ws.WL[L - 1];
             const size_t lds = 6 * (size_t)((Ws + 6) & ~3);
             hipLaunchKernelGGL((gabor_down_kernel<false>), dim3(Hp, B), block, lds, GCS_STREAM_OF(L),
                                (const uint8_t *)(wsb + ws.img_off[L - 1]), (size_t)B * 3 * Hs * Ws, Hs, Ws, HL, WL, Hp, Wp,
-                               planes, img_out);
+                               planes, img_out, flag_zero(0));
         }
         GCS_GABOR_CHECK("gcs_gabor_features(pad)");
     }
@@ -981,20 +1144,20 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
                 if (total_ll > 0x3fffffffLL) return gcs_fail(GCS_EINVAL, "gcs_gabor_features: too many tiles");
                 v.tile_end = (int)total_ll;
                 v.L = L;
-                v.offL = lo.off[L];
+                v.offL = lo.split ? lo.sl0[L] : lo.off[L];
             }
             for (int i = L1 - L0; i < GCS_LEVELS_MAX; ++i) {      // unused entries: never selected (tile < total_tiles)
                 G.lv[i] = G.lv[L1 - L0 - 1];
                 G.lv[i].tile_end = 0x7fffffff;
             }
             const int total_tiles = (int)total_ll;
-            const GaborSlab slab{lo.bx_n, lo.ntiles, lo.tile_bytes};
+            const GaborSlab slab{lo.bx_n, lo.ntiles, lo.tile_bytes, lo.img_bytes, lo.S, lo.mid_off, lo.top_off, lo.flag_off};
             // persistent grid: one workgroup per resident slot (two 54 KB workgroups per CU)
             const int slots = gcs_cu_count() * 2;
             const dim3 grid(total_tiles < slots ? total_tiles : slots, grouped ? MT : 1);
-#define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                            \
-    hipLaunchKernelGGL((gabor_mfma_kernel<MT_, GQ_, KS_, LV_, FA_>), grid, block, 0, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,  \
-                       reinterpret_cast<unsigned char *>(feats), total_tiles, slab)
+#define GCS_GABOR_LAUNCH4(MT_, GQ_, KS_, LV_, FA_)                                                                     \
+    gabor_launch<MT_, GQ_, KS_, LV_, FA_>(lo.split != 0, grid, block, GCS_STREAM_OF(L0), G, FLg, 4 * mt0, shift,          \
+                                          reinterpret_cast<unsigned char *>(feats), total_tiles, slab)
             // single launches of level 0 / level 1 (every bank of at most two levels) compile that level's store path alone
 #define GCS_GABOR_LAUNCH3(MT_, GQ_, KS_, FA_)                                       \
     do {                                                                            \
@@ -1101,9 +1264,7 @@ __global__ void unpack_kernel(const unsigned char *__restrict__ feats, GcsLayout
         const size_t pl = i / hw;
         const int rem = (int)(i % hw);
         const int b = (int)(pl / lo.D), d = (int)(pl % lo.D);
-        const uint16_t v = *reinterpret_cast<const uint16_t *>(
-            feats + gcs_slab_offset(lo, b, gcs_plane_of_logical(lo, d), rem / lo.W, rem % lo.W));
-        out[i] = v ^ 0x8080u;
+        out[i] = (uint16_t)gcs_slab_value(feats, lo, b, gcs_plane_of_logical(lo, d), rem / lo.W, rem % lo.W);
     }
 }
 

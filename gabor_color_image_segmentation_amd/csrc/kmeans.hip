@@ -29,8 +29,7 @@ __global__ void kmeans_init_kernel(const unsigned char *__restrict__ feats, GcsL
         const int j = i / lo.D, d = i % lo.D;
         const long p = ((2L * j + 1) * P) / (2L * k);
         const int y = (int)(p / lo.W), x = (int)(p % lo.W);
-        cent[((size_t)set * k + j) * lo.D + d] =
-            *reinterpret_cast<const uint16_t *>(feats + gcs_slab_offset(lo, set, gcs_plane_of_logical(lo, d), y, x)) ^ 0x8080u;
+        cent[((size_t)set * k + j) * lo.D + d] = (uint16_t)gcs_slab_value(feats, lo, set, gcs_plane_of_logical(lo, d), y, x);
     }
 }
 
@@ -53,9 +52,7 @@ __global__ void features_gather_kernel(const unsigned char *__restrict__ feats, 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * lo.D; i += gridDim.x * blockDim.x) {
         const int r = i / lo.D, d = i % lo.D;
         const int b = byx[3 * r], y = byx[3 * r + 1], x = byx[3 * r + 2];
-        out[i] = b < 0 ? (uint16_t)0
-                       : (uint16_t)(*reinterpret_cast<const uint16_t *>(
-                                        feats + gcs_slab_offset(lo, b, gcs_plane_of_logical(lo, d), y, x)) ^ 0x8080u);
+        out[i] = b < 0 ? (uint16_t)0 : (uint16_t)gcs_slab_value(feats, lo, b, gcs_plane_of_logical(lo, d), y, x);
     }
 }
 
@@ -79,6 +76,7 @@ extern "C" int gcs_features_gather(const uint16_t *feats, int B, int H, int W, i
 constexpr int KM_CHUNK = 128;
 
 // two horizontally adjacent pixels (x even) of physical plane r: one aligned dword on level 0, the same parent twice above
+// (wide slab: feature vectors of 208 or more planes never take the split one)
 __device__ __forceinline__ unsigned feature_pair(const unsigned char *feats, const GcsLayout &lo, int b, int r, int y, int x) {
     const unsigned char *p = feats + gcs_slab_offset(lo, b, r, y, x);
     if (r < lo.DL[0]) return *reinterpret_cast<const unsigned *>(p) ^ 0x80808080u;
@@ -272,9 +270,13 @@ constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 2
 // WAVES = 4 (narrow pass: wave w owns block w of the tile) or 8 (wide pass: 131 KB of LDS allow one workgroup per CU, so
 // it brings 8 waves: wave w works on block w & 3; in the assign phase it takes the block's 32-pixel half w >> 2, in the
 // update phase all 64 pixels for half of the plane tiles -> half the accumulators, twice the waves to hide latency).
-template <int KT, int NST, int DSTEPS, int WAVES>
+// SPLIT (round 6): the split slab of csrc/common.h (narrow pass only). NST then counts staging ROUNDS: an ITEM = 16 consecutive slots of a
+// tile = 16 low bytes + 8 bytes of MID nibbles (+ 8 bytes of TOP nibbles when the tile's flag word says that one of them is set),
+// unpacked into the same LDS image as the wide slab's: 16 pixels of a level-0 plane row, or the 4 x 4 parents of one block of a
+// level-1 plane, replicated over the block's 64 pixels.
+template <int KT, int NST, int DSTEPS, int WAVES, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
-                                          : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= 6 ? GCS_KP_WAVES
+                                          : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= (SPLIT ? 3 : 6) ? GCS_KP_WAVES
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials, void *__restrict__ raster,
@@ -290,6 +292,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     __shared__ __attribute__((aligned(16))) unsigned char s_coarse[KP_COARSE];
     __shared__ __attribute__((aligned(16))) unsigned char s_lab[KP_TP];
     __shared__ long long s_const[16];
+    constexpr int KP_FLAGS = 320;                            // tiles of one workgroup whose flag is kept (more: read as set, always exact)
+    __shared__ unsigned char s_flag[SPLIT ? KP_FLAGS : 4];
+    static_assert(!SPLIT || (DSTEPS == KP_DSTEPS_NARROW && WAVES == 4), "the split slab is the narrow pass's");
 
     // either output may be absent (host contract): raster == NULL on the passes whose assignment nobody reads (every
     // pass but the last), partials == NULL on the last pass, whose sums nobody reads (no update phase, no fold)
@@ -309,8 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     const int nimg = per_image ? 1 : (int)gridDim.y;
     const int G = parts * nimg, g = per_image ? part : b * parts + part;
     const int nlist = ntiles * nimg;
-    const size_t img0 = per_image ? (size_t)b * ntiles : 0;               // first tile of the list in the slab
-    const unsigned char *fb = feats + img0 * lo.tile_bytes;               // each tile one contiguous run
+    const unsigned char *fb = feats + (size_t)(per_image ? b : 0) * lo.img_bytes;   // first image of the list (wide: each tile one contiguous run)
 
     // ---- centroids -> LDS scratch (borrowed from the tile buffer): [8*KT clusters][KP_ROWS planes] u16 in PHYSICAL
     //      plane order, stored offset-binary (c ^ 0x8080: low byte = digit cl, high byte = digit ch), zero outside K x D.
@@ -323,6 +327,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         if (lo.n_levels > 2 && r >= lo.row0[2] && r < lo.row0[2] + lo.DL[2]) e = kp_logical_of<2>(lo, r - lo.row0[2]);
         if (lo.n_levels > 3 && r >= lo.row0[3] && r < lo.row0[3] + lo.DL[3]) e = kp_logical_of<3>(lo, r - lo.row0[3]);
         cs[i] = (j < K && r < D) ? (uint16_t)(cset[j * D + e] ^ 0x8080u) : (uint16_t)0;
+    }
+    if constexpr (SPLIT) {
+        // the flag words of this workgroup's tiles (csrc/common.h): is any TOP nibble of the tile non-zero?
+        for (int it = tid; it < KP_FLAGS; it += NTHR) {
+            const long long lt = (long long)g + (long long)it * G;
+            unsigned char f = 0;
+            if (lt < nlist) {
+                const int T = reverse ? nlist - 1 - (int)lt : (int)lt;
+                const int bi = T / ntiles, tn = T - bi * ntiles;
+                f = *reinterpret_cast<const unsigned *>(fb + (size_t)bi * lo.img_bytes + lo.flag_off + 4 * (size_t)tn) != 0u;
+            }
+            s_flag[it] = f;
+        }
     }
     __syncthreads();
     // ---- per-cluster key base (exact int64): 16 * (|c|^2 - 2*(offset terms of the -128 digits)) + j.
@@ -390,10 +407,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     //      Loads and LDS writes are UNCONDITIONAL per wave: a per-chunk guard makes hipcc branch around every
     //      load / write with exec masking and drain vmcnt(0) before each write. Chunks beyond the tile
     //      are clamped to its last chunk: they re-read and re-write it with its own data.
-    const int n0 = 32 * lo.DL[0];                      // level-0 chunks
+    const int n0 = SPLIT ? 16 * lo.DL[0] : 32 * lo.DL[0];   // level-0 chunks (split slab: level-0 items)
     const int n1 = lo.n_levels > 1 ? 8 * lo.DL[1] : 0; // level-1 chunks
-    const int nchunk = lo.tile_bytes >> 4;
+    const int nchunk = SPLIT ? lo.S >> 4 : lo.tile_bytes >> 4;   // (split slab: items per tile)
     v4i st[NST];
+    v2i sm[NST], stt[NST];                             // split slab: MID and TOP nibbles of the item
     int sdst[NST], ssrc[NST];
     int scls[NST];                                     // wave-uniform: 0 = every lane copies, 1 = every lane replicates, 2 = mixed
     bool sl1[NST];
@@ -402,11 +420,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         const int ci = min(tid + NTHR * i, nchunk - 1);
         ssrc[i] = ci;
         const int c1 = ci - n0;
-        const bool l1 = c1 >= 0 && c1 < n1;
+        const bool l1 = SPLIT ? c1 >= 0 : c1 >= 0 && c1 < n1;
         sl1[i] = l1;
-        sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
-                  : l1    ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 3)) * KP_PITCH + (c1 & 7) * 64]
-                          : (int)(size_t)&s_coarse[(c1 - n1) * 16];
+        if constexpr (SPLIT)   // level-0 item: 16 pixels of plane row ci >> 4; level-1 item: block c1 & 3 of plane c1 >> 2 (128 bytes of its row)
+            sdst[i] = l1 ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 128]
+                         : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (ci & 15) * 32];
+        else
+            sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
+                      : l1    ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 3)) * KP_PITCH + (c1 & 7) * 64]
+                              : (int)(size_t)&s_coarse[(c1 - n1) * 16];
         const unsigned long long m = __builtin_amdgcn_ballot_w64(l1);
         scls[i] = m == 0ull ? 0 : m == ~0ull ? 1 : 2;
     }
@@ -415,41 +437,102 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 #pragma unroll
         for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[ssrc[i]], nt_loads);
     };
+    // split slab: tile `tn` of image `bi` of the list; the TOP nibbles only when the tile's flag word is set (they are zero otherwise)
+    auto stage_load_split = [&](int bi, int tn, bool top) {
+        const unsigned char *ib = fb + (size_t)bi * lo.img_bytes;
+        const v4i *pl = reinterpret_cast<const v4i *>(ib + (size_t)tn * lo.S);
+        const v2i *pm = reinterpret_cast<const v2i *>(ib + lo.mid_off + (size_t)tn * (lo.S >> 1));
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            st[i] = kp_load(&pl[ssrc[i]], nt_loads);
+            sm[i] = kp_load(&pm[ssrc[i]], nt_loads);
+        }
+        if (top) {
+            const v2i *pt = reinterpret_cast<const v2i *>(ib + lo.top_off + (size_t)tn * (lo.S >> 1));
+#pragma unroll
+            for (int i = 0; i < NST; ++i) stt[i] = kp_load(&pt[ssrc[i]], nt_loads);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) stt[i] = v2i{0, 0};
+        }
+    };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
+    // a level-1 chunk of the LDS image: coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice,
+    // each row into two fine rows = four 16-byte pieces of a 64-byte region at `dst`. Lanes are 64 bytes apart, so piece k
+    // of lanes l and l+2 would share banks (4-way conflicts: SQ_LDS_BANK_CONFLICT 0.4 M -> 17.7 M cycles per
+    // launch when every lane wrote its pieces in the same order). Lanes therefore start on different pieces:
+    // bit 2 of the lane picks which coarse row goes first, bit 1 which of its two pieces; the eight lanes of a
+    // ds_write_b128 group then cover 32 distinct banks.
+    auto replicate_write = [&](int dst, const v4i v) {
+        const bool f = (lane >> 2) & 1;
+        const unsigned x0 = f ? (unsigned)v[2] : (unsigned)v[0], x1 = f ? (unsigned)v[3] : (unsigned)v[1];
+        const unsigned y0 = f ? (unsigned)v[0] : (unsigned)v[2], y1 = f ? (unsigned)v[1] : (unsigned)v[3];
+        v4i ra, rb;
+        ra[0] = (int)__builtin_amdgcn_perm(0u, x0, 0x01000100u);
+        ra[1] = (int)__builtin_amdgcn_perm(0u, x0, 0x03020302u);
+        ra[2] = (int)__builtin_amdgcn_perm(0u, x1, 0x01000100u);
+        ra[3] = (int)__builtin_amdgcn_perm(0u, x1, 0x03020302u);
+        rb[0] = (int)__builtin_amdgcn_perm(0u, y0, 0x01000100u);
+        rb[1] = (int)__builtin_amdgcn_perm(0u, y0, 0x03020302u);
+        rb[2] = (int)__builtin_amdgcn_perm(0u, y1, 0x01000100u);
+        rb[3] = (int)__builtin_amdgcn_perm(0u, y1, 0x03020302u);
+        const int e16 = ((lane >> 1) & 1) * 16, f32 = f ? 32 : 0;
+        *reinterpret_cast<lds_v4i_ptr>(dst + f32 + e16) = ra;
+        *reinterpret_cast<lds_v4i_ptr>(dst + f32 + 16 - e16) = ra;
+        *reinterpret_cast<lds_v4i_ptr>(dst + 32 - f32 + e16) = rb;
+        *reinterpret_cast<lds_v4i_ptr>(dst + 32 - f32 + 16 - e16) = rb;
+    };
+    // split slab: the high bytes (XOR 0x80) of the first and the second half of a nibble group from its MID and TOP dwords
+    auto split_hi = [&](unsigned mid, unsigned top, unsigned &e, unsigned &o) {
+        e = ((mid & 0x0f0f0f0fu) | ((top << 4) & 0xf0f0f0f0u)) ^ 0x80808080u;
+        o = (((mid >> 4) & 0x0f0f0f0fu) | (top & 0xf0f0f0f0u)) ^ 0x80808080u;
+    };
     auto stage_write = [&]() {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const v4i v = st[i];
-            if (scls[i] == 0) {
+            if constexpr (SPLIT) {
+                const v2i m = sm[i], t = stt[i];
+                auto level0 = [&]() {
+                    // two groups of 8 pixels: low bytes (a, b), high bytes e (pixels 0..3) and o (pixels 4..7) -> u16 pairs
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        unsigned e, o;
+                        split_hi((unsigned)m[g], (unsigned)t[g], e, o);
+                        const unsigned a = (unsigned)v[2 * g], bb = (unsigned)v[2 * g + 1];
+                        v4i w;
+                        w[0] = (int)__builtin_amdgcn_perm(e, a, 0x05010400u);
+                        w[1] = (int)__builtin_amdgcn_perm(e, a, 0x07030602u);
+                        w[2] = (int)__builtin_amdgcn_perm(o, bb, 0x05010400u);
+                        w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
+                        *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 16 * g) = w;
+                    }
+                };
+                auto level1 = [&]() {
+                    // two halves of the block's 4 x 4 parents: parent rows (2 hh, 2 hh + 1), a nibble group = one parent row
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        unsigned e, o;                                   // e = (r0 p0, r0 p1, r1 p0, r1 p1), o = (r0 p2, r0 p3, r1 p2, r1 p3)
+                        split_hi((unsigned)m[hh], (unsigned)t[hh], e, o);
+                        const unsigned a = (unsigned)v[2 * hh], bb = (unsigned)v[2 * hh + 1];
+                        v4i w;
+                        w[0] = (int)__builtin_amdgcn_perm(e, a, 0x05010400u);
+                        w[1] = (int)__builtin_amdgcn_perm(o, a, 0x05030402u);
+                        w[2] = (int)__builtin_amdgcn_perm(e, bb, 0x07010600u);
+                        w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
+                        replicate_write(sdst[i] + 64 * hh, w);
+                    }
+                };
+                if (scls[i] == 0) level0();
+                else if (scls[i] == 1) level1();
+                else if (sl1[i]) level1();
+                else level0();
+            } else if (scls[i] == 0) {
                 *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
-            } else {
-                // coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice, each row into
-                // two fine rows = four 16-byte pieces of this lane's 64-byte region. Lanes are 64 bytes apart, so piece k
-                // of lanes l and l+2 would share banks (4-way conflicts: SQ_LDS_BANK_CONFLICT 0.4 M -> 17.7 M cycles per
-                // launch when every lane wrote its pieces in the same order). Lanes therefore start on different pieces:
-                // bit 2 of the lane picks which coarse row goes first, bit 1 which of its two pieces; the eight lanes of a
-                // ds_write_b128 group then cover 32 distinct banks.
-                const bool f = (lane >> 2) & 1;
-                const unsigned x0 = f ? (unsigned)v[2] : (unsigned)v[0], x1 = f ? (unsigned)v[3] : (unsigned)v[1];
-                const unsigned y0 = f ? (unsigned)v[0] : (unsigned)v[2], y1 = f ? (unsigned)v[1] : (unsigned)v[3];
-                v4i ra, rb;
-                ra[0] = (int)__builtin_amdgcn_perm(0u, x0, 0x01000100u);
-                ra[1] = (int)__builtin_amdgcn_perm(0u, x0, 0x03020302u);
-                ra[2] = (int)__builtin_amdgcn_perm(0u, x1, 0x01000100u);
-                ra[3] = (int)__builtin_amdgcn_perm(0u, x1, 0x03020302u);
-                rb[0] = (int)__builtin_amdgcn_perm(0u, y0, 0x01000100u);
-                rb[1] = (int)__builtin_amdgcn_perm(0u, y0, 0x03020302u);
-                rb[2] = (int)__builtin_amdgcn_perm(0u, y1, 0x01000100u);
-                rb[3] = (int)__builtin_amdgcn_perm(0u, y1, 0x03020302u);
-                if (scls[i] == 1 || sl1[i]) {
-                    const int e16 = ((lane >> 1) & 1) * 16, f32 = f ? 32 : 0;
-                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + e16) = ra;
-                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + 16 - e16) = ra;
-                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + e16) = rb;
-                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + 16 - e16) = rb;
-                } else {                                  // a lane of a mixed wave whose chunk is not level 1
-                    *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
-                }
+            } else if (scls[i] == 1 || sl1[i]) {
+                replicate_write(sdst[i], v);
+            } else {                                      // a lane of a mixed wave whose chunk is not level 1
+                *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
             }
         }
     };
@@ -488,7 +571,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     // Infinity Cache.
     auto phys = [&](int lt) { return reverse ? nlist - 1 - lt : lt; };
     int ltile = g;
-    if (ltile < nlist) stage_load(phys(ltile));
+    if constexpr (!SPLIT) {
+        if (ltile < nlist) stage_load(phys(ltile));
+    }
     // this wave's block (one 8x8 block per wave) as (block row, block column) inside ITS image, advanced without a
     // division: which pixels exist and vote is decided from it. A step moves the tile index inside the image by
     // s1 = G mod ntiles, or by s1 - ntiles when that runs past the image's last tile (global list only).
@@ -502,6 +587,24 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         by = blk0 / lo.bx_n;
         bx = blk0 - by * lo.bx_n;
     }
+    // split slab: (image of the list, tile inside it) of the tile that is LOADED next - one step ahead of `tin` -, advanced like
+    // `tin`: s1 tiles on / back modulo the image, qG (+ 1 on a wrap) images on / back; and the iteration whose flag that load needs
+    const int qG = __builtin_amdgcn_readfirstlane(G / ntiles);
+    int tin_l = tin, bimg_l = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) / ntiles), it_l = 0;
+    auto tile_has_top = [&](int it) -> bool {
+        return __builtin_amdgcn_readfirstlane(it < KP_FLAGS ? (int)s_flag[it < KP_FLAGS ? it : 0] : 1) != 0;
+    };
+    auto load_next_split = [&]() {
+        stage_load_split(bimg_l, tin_l, tile_has_top(it_l));
+        const int tn = reverse ? tin_l - s1 : tin_l + s1;
+        const bool wrap = reverse ? tn < 0 : tn >= ntiles;
+        tin_l = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
+        bimg_l += reverse ? -(qG + (wrap ? 1 : 0)) : qG + (wrap ? 1 : 0);
+        ++it_l;
+    };
+    if constexpr (SPLIT) {
+        if (ltile < nlist) load_next_split();
+    }
     for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
         stage_write();
@@ -509,9 +612,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
         // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
         __builtin_amdgcn_s_setprio(3);
-        if (ltile + G < nlist) stage_load(phys(ltile + G));   // in flight during the MFMAs
+        if (ltile + G < nlist) {                              // in flight during the MFMAs
+            if constexpr (SPLIT) load_next_split();
+            else stage_load(phys(ltile + G));
+        }
         __builtin_amdgcn_s_setprio(0);
-        if (lo.n_levels > 2) {
+        if (!SPLIT && lo.n_levels > 2) {
             expand_deep();
             __syncthreads();
         }
@@ -1294,7 +1400,8 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         // (assign_accumulate with labels: every pixel of the image is labelled, halo rows of a row window included)
         void *lab_out = raster ? raster : static_cast<void *>(labels);
         const int lab_u8 = raster ? raster_u8 : 1;
-        const int nt_flag = (size_t)B * lo.ntiles * lo.tile_bytes >= KP_NT_MIN_SLAB_BYTES ? 1 : 0;   // see kp_load
+        // see kp_load: the bytes a pass streams (a split slab: three quarters of the feature bytes)
+        const int nt_flag = (size_t)B * lo.ntiles * (lo.split ? lo.tile_bytes / 4 * 3 : lo.tile_bytes) >= KP_NT_MIN_SLAB_BYTES ? 1 : 0;
 #define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
@@ -1302,7 +1409,17 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
 #define GCS_KP_LAUNCH(KT_, NST_, DS_) GCS_KP_LAUNCHW(KT_, NST_, DS_, 4)
         const int nchunk = lo.tile_bytes / 16;
         const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
-        if (D < 16 * KP_DSTEPS_NARROW) {
+        if (lo.split) {                                               // (D < 80, at most two levels: csrc/common.h)
+            const int rounds = ((lo.S >> 4) + 255) / 256;             // staging rounds: items of 16 slots per thread
+#define GCS_KP_LAUNCHS(KT_, NR_)                                                                                            \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NR_, KP_DSTEPS_NARROW, 4, true>), dim3(parts, B), dim3(256), 0, stream, \
+                       reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,             \
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
+            if (k <= 8 && rounds <= 3) { GCS_KP_LAUNCHS(1, 3); }
+            else if (k <= 8) { GCS_KP_LAUNCHS(1, 5); }
+            else { GCS_KP_LAUNCHS(2, 5); }
+#undef GCS_KP_LAUNCHS
+        } else if (D < 16 * KP_DSTEPS_NARROW) {
             if (k <= 8) {
                 if (nst <= 3) { GCS_KP_LAUNCH(1, 3, KP_DSTEPS_NARROW); }
                 else if (nst <= 6) { GCS_KP_LAUNCH(1, 6, KP_DSTEPS_NARROW); }

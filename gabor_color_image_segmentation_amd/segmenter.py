@@ -109,18 +109,18 @@ class _CaptureGuard:
                 self._drain()
 
     def retire(self, entries):
-        """Drop graph entries (dicts holding a CUDAGraph and its buffers): now if no capture is open, else after it."""
-        entries = [e for e in entries if e is not None]
-        if not entries:
-            return
+        """Drop graph entries (dicts holding a CUDAGraph and its buffers): now if no capture is open, else after it. ``entries``
+        is a LIST the caller gives up: it is emptied here, so that the last references die inside the locked region (or move to
+        the parking list) and not later, when the caller's frame unwinds and another thread may have opened a capture."""
         if self._lock.acquire(blocking=False):
             try:
                 self._drain()
-                del entries[:]       # (the last references, unless the caller keeps some: freed here, outside any capture)
+                entries.clear()      # (the last references: the graphs are destroyed here, under the lock, outside any capture)
             finally:
                 self._lock.release()
         else:
-            self._parked.extend(entries)      # list.extend is atomic under the GIL; drained by the capturer
+            self._parked.extend(e for e in entries if e is not None)      # drained by the capturer, under the lock
+            entries.clear()
 
     def _drain(self):
         while self._parked:

@@ -34,7 +34,7 @@ enum {
     GCS_EHIP = 2    /* HIP runtime error at launch */
 };
 
-#define GCS_ABI_VERSION 17
+#define GCS_ABI_VERSION 18
 #define GCS_KSIZE_MAX 15  /* tap frame: 15 rows x 16 columns (SPEC.md §2) */
 #define GCS_K_MAX 16      /* clusters */
 #define GCS_TAP_ABS_SUM_MAX 32896 /* per filter and part: 255 * sum|tapq| < 2^23 (gcs_bank_pack rejects larger banks) */
@@ -69,6 +69,14 @@ int gcs_bank_pack(const int16_t *tapq, int n_scales, int n_orient, int ksize, in
  * canonical [B][D][H][W] uint16 tensor of SPEC.md §3. "Label slab": a uint8 label map in RASTER order, [B][H][W]
  * (gcs_label_slab_bytes = B*H*W rounded up to 16). */
 size_t gcs_feature_slab_bytes(int B, int H, int W, int n_scales, int n_orient);
+/* ABI 18: banks of at most two pyramid levels with D <= 79 (every 4x6-style bank) keep the slab SPLIT: per image three planar
+ * arrays in the same tile / plane / slot order - the low bytes, bits 8..11 and bits 12..15 of every value - and one flag word
+ * per tile that says whether any of the tile's bits 12..15 is set (values of 4096 and more are 6e-5 of what BSD500 produces:
+ * profiles/r6_notes.md). A Lloyd pass streams the first two arrays and, for flagged tiles only, the third: exact for any data.
+ * gcs_feature_slab_bytes(B, ...) == B * gcs_feature_slab_bytes(1, ...) for every bank: image b's slab starts at b times that
+ * (callers may hand a sub-batch's part of a slab to any entry point). gcs_feature_pass_bytes: the feature bytes ONE Lloyd
+ * pass reads when no tile is flagged (3/4 of the feature bytes of a split slab, all of them otherwise; padding included). */
+size_t gcs_feature_pass_bytes(int B, int H, int W, int n_scales, int n_orient);
 size_t gcs_label_slab_bytes(int B, int H, int W);
 /* uint64 partial sums written by one assign pass: one row of k * (D+1) values per k-means workgroup, stored in chunks
  * of 16 elements, padded (opaque: only gcs_kmeans_reduce / gcs_kmeans_reduce_finalize read them). */

@@ -22,7 +22,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gcs.h but not exported"
-    assert lib.gcs_abi_version() == 17
+    assert lib.gcs_abi_version() == 18
 
 
 def test_no_torch_types_in_the_abi():
@@ -38,13 +38,21 @@ def test_geometry(lib):
     tiles = (blocks + 3) // 4
     packed_tiles = (60 * 40 + 11 + 15 + 3) // 4                 # 607 instead of 626 tiles: 0.6 % padding instead of 3.7 %
     tile_bytes = 36 * 256 * 2 + 36 * 64 * 2                     # 4x6 bank: 12 filters x 3 channels on levels 0 and 1
-    assert lib.gcs_feature_slab_bytes(64, 321, 481, 4, 6) == 64 * packed_tiles * tile_bytes
-    assert lib.gcs_feature_slab_bytes(64, 481, 321, 4, 6) == 64 * ((60 * 40 + 16 + 10 + 3) // 4) * tile_bytes   # portrait: 241 / 160 parents
-    assert lib.gcs_feature_slab_bytes(1, 322, 482, 2, 3) == ((60 * 40 + 11 + 15 + 3) // 4) * 18 * 256 * 2       # two-pixel strips pack too
-    assert lib.gcs_feature_slab_bytes(1, 323, 480, 2, 3) == ((60 * 41 + 3) // 4) * 18 * 256 * 2                 # a 3-row edge does not
+    # banks of at most two levels with D <= 79 take the SPLIT slab (round 6): the same 16 bits per value in three planar arrays
+    # (low byte | bits 8..11 | bits 12..15) plus one 4-byte flag word per tile, rounded up to 256 bytes per image
+    flags = lambda t: -(-4 * t // 256) * 256
+    assert lib.gcs_feature_slab_bytes(64, 321, 481, 4, 6) == 64 * (packed_tiles * tile_bytes + flags(packed_tiles))
+    pt = (60 * 40 + 16 + 10 + 3) // 4                           # portrait: 241 / 160 parents
+    assert lib.gcs_feature_slab_bytes(64, 481, 321, 4, 6) == 64 * (pt * tile_bytes + flags(pt))
+    assert lib.gcs_feature_slab_bytes(1, 322, 482, 2, 3) == packed_tiles * 18 * 256 * 2 + flags(packed_tiles)   # two-pixel strips pack too
+    t3 = (60 * 41 + 3) // 4
+    assert lib.gcs_feature_slab_bytes(1, 323, 480, 2, 3) == t3 * 18 * 256 * 2 + flags(t3)                       # a 3-row edge does not
+    assert lib.gcs_feature_slab_bytes(7, 321, 481, 4, 6) == 7 * lib.gcs_feature_slab_bytes(1, 321, 481, 4, 6)   # image-major: slabs slice by image
+    assert lib.gcs_feature_pass_bytes(64, 321, 481, 4, 6) == 64 * packed_tiles * tile_bytes * 3 // 4           # a pass streams 12 of the 16 bits
+    assert lib.gcs_feature_pass_bytes(1, 321, 481, 8, 8) == lib.gcs_feature_slab_bytes(1, 321, 481, 8, 8)      # deep banks: the wide slab
     assert lib.gcs_feature_slab_bytes(1, 321, 481, 8, 8) == tiles * 48 * (256 + 64 + 16 + 4) * 2
     assert lib.gcs_feature_slab_bytes(1, 321, 481, 7, 1) == tiles * (6 * 512 + 6 * 128 + 6 * 32 + 32)   # 3 planes x 4 px x 2 B = 24 -> 32
-    assert lib.gcs_feature_slab_bytes(1, 8, 8, 1, 1) == 3 * 512
+    assert lib.gcs_feature_slab_bytes(1, 8, 8, 1, 1) == 3 * 512 + 256
     assert lib.gcs_label_slab_bytes(2, 321, 481) == -(-2 * 321 * 481 // 16) * 16      # uint8 raster map
     assert lib.gcs_bank_packed_bytes(4, 6) == 6 * 8 * 64 * 16          # 12 filters per level -> 3 row tiles of 4 filters each
     assert lib.gcs_bank_packed_bytes(1, 1) == 8 * 64 * 16 and lib.gcs_bank_packed_bytes(8, 8) == 16 * 8 * 64 * 16

@@ -318,6 +318,38 @@ def test_config3_eight_hip_ranks_equal_unsharded_c_oracle(built):
 
 
 @pytest.mark.gpu
+def test_config3_at_its_stated_size_eight_hip_ranks_times_64_images(built):
+    """BASELINE config 3 AS IT IS STATED: batch 512 of 481 x 321 x 3, eight ranks x 64 images (bench.py's
+    sharding: rank r holds images [64 r, 64 (r + 1)) of the seed-0 batch), 4x6 bank, k = 8, n_iter = 10, one global codebook:
+    init broadcast + one int64 all-reduce per Lloyd pass on device tensors, all eight ranks through the HIP kernels (threads of
+    one process: the box admits six processes per card). EVERY label of the 512 maps == the C oracle's global-codebook result
+    on the unsharded 512-image batch (about a minute of OpenMP). No scaling curve is measured by this (one GPU): none is claimed."""
+    from threaded_world import run_threaded
+    from gabor_color_image_segmentation_amd import Segmenter
+    from gabor_color_image_segmentation_amd.synthetic import synthetic_shard
+    from oracle import c_oracle as co, spec_oracle as so
+    world, per_rank, height, width = 8, 64, 321, 481
+
+    def rank_fn(rank, world):
+        imgs = synthetic_shard(rank * per_rank, per_rank, height, width, seed=0)
+        seg = Segmenter(device="cuda:0")                                         # defaults = BASELINE config 3's bank, k, n_iter
+        return seg.segment_device(torch.from_numpy(imgs).cuda(), mode="global").cpu().numpy().astype(np.uint8)
+
+    got = np.concatenate(run_threaded(world, rank_fn))
+    assert got.shape == (512, height, width)
+    # the oracle, image by image (the stacked uint16 feature tensor of 512 images is 11.4 GB; co.segment_batch would hold it twice)
+    tapq, shift = so.bank()
+    feats = np.empty((world * per_rank, 72, height * width), np.uint16)
+    for r in range(world):
+        imgs = synthetic_shard(r * per_rank, per_rank, height, width, seed=0)
+        for i in range(per_rank):
+            feats[r * per_rank + i] = co.gabor_features(imgs[i], tapq, shift, 6).reshape(72, -1)
+    ref = co.kmeans(feats, 8, 10)[0].reshape(-1, height, width)
+    del feats
+    assert np.array_equal(got, ref.astype(np.uint8)) and len(np.unique(ref)) == 8
+
+
+@pytest.mark.gpu
 def test_config5_2048_in_eight_strips_of_256_rows_on_gpu(built):
     """BASELINE config 5 as SURVEY §8e specifies it: ONE 2048 x 2048 image, rank r owns rows [256 r, 256 (r + 1)), 12-row
     halos delivered with the strip (option (i)); eight ranks through the HIP kernels (threads of one process). The stitched

@@ -322,6 +322,21 @@ def test_a_refused_capture_warns_once_and_runs_eagerly(torch_cuda):
     assert np.array_equal(got[0], so.segment(img[0], n_iter=2)) and np.array_equal(got, again)
 
 
+def test_a_capture_invalidated_by_another_threads_device_synchronize(torch_cuda):
+    """The REAL failure path of a first call (the monkey-patched form is the test above): while thread A
+    captures a new shape's graph, thread B - standing for a caller's loader or logger - calls torch.cuda.synchronize() in a loop,
+    which HIP refuses during a capture and which invalidates that capture. tests/checkers/invalidated_capture_child.py checks
+    labels == oracle for the first and a second call, at most one warning, a later shape, and a normal process end; it runs in a
+    process of its own (two processes on the card) so that an abort would fail this test, not end the session."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "checkers", "invalidated_capture_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"child ended with {r.returncode}:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.strip().splitlines()[-1].startswith("OK capture"), r.stdout[-2000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
 def test_segment_stream_equals_segment_batch(torch_cuda):
     """The pipelined host API (three streams, depth + 1 buffer slots): seven batches through segment_stream give, in order,
     exactly what segment_batch gives for each - both label dtypes, both codebook modes, a depth larger than the input."""
@@ -427,10 +442,12 @@ def test_small_call_launch_forms_of_two_level_banks(torch_cuda, no, ks, b, h, w)
 
 @pytest.mark.parametrize("ns,no,ks,k", [(1, 1, 15, 3), (1, 4, 9, 5), (2, 5, 11, 8), (3, 8, 15, 16), (2, 13, 7, 4),
                                         (3, 9, 15, 4), (1, 43, 11, 5), (8, 8, 15, 8), (8, 8, 15, 13), (3, 23, 9, 16),
-                                        (3, 23, 9, 7)])
+                                        (3, 23, 9, 7), (6, 8, 15, 8), (5, 8, 13, 7), (8, 6, 13, 8), (7, 6, 11, 6)])
 def test_segment_small_and_ragged_feature_counts(torch_cuda, ns, no, ks, k):
     """D = 3, 12, 30, 72, 78: every staging-chunk bucket of the narrow MFMA k-means pass, D not a multiple of 8;
-    D = 81, 129, 192, 207: every bucket of the wide (208-row) pass, k <= 8 and k > 8."""
+    D = 81, 129, 192, 207: every bucket of the wide (208-row) pass, k <= 8 and k > 8. The last four are the
+    deep-bank pass's remaining instantiations: 6x8 and 5x8 (three levels, 48 planes on level 0: kmeans_pass_native_kernel
+    <3, 3, 6>), 8x6 and 7x6 (four levels of 36 planes: <4, 2, 0>, the two-workgroups-per-CU table form)."""
     from gabor_color_image_segmentation_amd import Segmenter
     imgs = _synth(2, 40, 72, seed=31)
     seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=4)
@@ -462,10 +479,26 @@ def test_global_codebook_batch_list_walk(torch_cuda, b, h, w):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("ns,no", [(4, 6), (8, 8), (3, 23)])
+@pytest.mark.parametrize("ns,no,b", [(6, 8, 5), (8, 6, 5), (5, 8, 400), (7, 6, 3)])
+def test_deep_bank_pass_global_codebook_batches(torch_cuda, ns, no, b):
+    """the deep-bank pass's <3, 3, 6> and <4, 2, 0> forms with a batch and ONE global codebook: the batch-list walk,
+    reverse sweeps (4 passes) and - 400 small images of 4 tiles - fewer resident slots per image than partial rows (parts_eff 1 < parts 2),
+    every label against the C oracle."""
+    from oracle import c_oracle as co
+    from gabor_color_image_segmentation_amd import Segmenter
+    h, w = (56, 88) if b < 10 else (24, 40)
+    imgs = _synth(b, h, w, seed=90 + b)
+    seg = Segmenter(n_scales=ns, n_orient=no, k=7, n_iter=4)
+    got = seg.segment_batch(imgs, mode="global")
+    ref = co.segment_batch(imgs, seg.bank.tapq, seg.bank.shift, seg.bank.n_orient, k=7, n_iter=4, mode="global")
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("ns,no", [(4, 6), (8, 8), (3, 23), (6, 8), (5, 8), (8, 6), (7, 6)])
 def test_lloyd_pass_with_one_output_only(torch_cuda, ns, no):
     """`labels_dev == NULL` (passes whose assignment nobody reads) and `partials_dev == NULL` (the last pass) give the
-    same labels / the same partial sums as the call with both outputs: narrow, wide (8-wave) and generic pass."""
+    same labels / the same partial sums as the call with both outputs: narrow, wide (8-wave) and generic pass, and every
+    instantiation of the deep-bank pass (8x8, 6x8, 5x8, 8x6, 7x6)."""
     import torch
     from gabor_color_image_segmentation_amd import Segmenter
     b, h, w = 3, 56, 88

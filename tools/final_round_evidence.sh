@@ -4,7 +4,7 @@
 # GPU tests -> driver-style bench line -> round profile (kernel stats, HBM traffic) -> config-4 profile -> SQ counters ->
 # scoring kernel stats -> one-image graph timeline -> steady-state Gabor stage timeline. Summaries land in gpurun_out/profiles/.
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 O=$R/gpurun_out; P=$O/profiles
 mkdir -p $P

@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-other-mode > $OUT/bench_trace.log 2>&1
 grep '"metric"' $OUT/bench_trace.log > $R/gpurun_out/profiles/${TAG}_bench_under_rocprof.json || true
 cp $OUT/trace/*/*kernel_stats.csv $R/gpurun_out/profiles/${TAG}_kernel_stats.csv
+cp $R/gpurun_out/profiles/${TAG}_kernel_stats.csv $R/gpurun_out/profiles/kernel_stats_latest.csv   # bench.py: roofline.frac_rocprof
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-other-mode > $OUT/bench_$c.log 2>&1
 done

@@ -130,6 +130,43 @@ __global__ __launch_bounds__(256, WGS) void stream_d(const v4i *__restrict__ src
     if (acc == 0x12345678) out[0] = 1;
 }
 
+// variant F (round 6): the NARROW tile of the split slab (12-bit base: NI items of 16 low bytes + 8 bytes of nibbles, the low bytes
+// of the whole tile first, then its nibbles): NR = ceil(NI / 256) rounds of one 16-byte and one 8-byte load per thread (clamped
+// to the last item), the LDS image at full width (32 bytes per item), same 2 barriers per tile, no compute.
+typedef int v2i __attribute__((ext_vector_type(2)));
+template <int NI, int WGS, int STRIDE = NI * 24>
+__global__ __launch_bounds__(256, WGS) void stream_f(const unsigned char *__restrict__ src, int ntiles, int parts, int *out) {
+    constexpr int NR = (NI + 255) / 256;
+    __shared__ v4i lds[2 * NI + 128];
+    const int tid = threadIdx.x;
+    v4i lo[NR]; v2i mid[NR];
+    int acc = 0;
+    int tile = blockIdx.x;
+    auto load = [&](int t) {
+        const unsigned char *tb = src + (size_t)t * STRIDE;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int it = min(tid + 256 * i, NI - 1);
+            lo[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(tb) + it);
+            mid[i] = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(tb + NI * 16) + it);
+        }
+    };
+    if (tile < ntiles) load(tile);
+    for (; tile < ntiles; tile += parts) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int it = min(tid + 256 * i, NI - 1);
+            lds[2 * it + (i >> 1)] = lo[i];
+            lds[2 * it + 1 + (i >> 1)] = v4i{mid[i][0], mid[i][1], mid[i][0], mid[i][1]};
+        }
+        __syncthreads();
+        if (tile + parts < ntiles) load(tile + parts);
+        acc ^= lds[(tid * 7) % (2 * NI)][0];
+        __syncthreads();
+    }
+    if (acc == 0x12345678) out[0] = 1;
+}
+
 int main() {
     const size_t bytes = (size_t)64 * 612 * 36864;        // 64 images x 612 tiles x 36 KB (all variants stay inside)
     const size_t n16 = bytes / 16;
@@ -217,6 +254,32 @@ int main() {
                 time3([&] { stream_e<2048, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 32 768 B tiles, 4 WG/CU, one list of 1024");
             }
         }
+    }
+    {
+        // round 6: the 12-bit base tiles of the split slab: 17 280 B (4x6 bank; 720 items) and 24 480 B (8x8 bank; 1 020 items),
+        // 607 tiles per 321x481 image, one list of the whole batch; E = plain 16-byte chunks, F = the real (16 + 8)-byte items
+        const int tpi = 607;
+        auto time4 = [&](auto launch, const char *name, size_t b2) {
+            launch(); hipDeviceSynchronize();
+            float best = 1e9, sum = 0;
+            for (int r = 0; r < 10; ++r) { hipEventRecord(s); launch(); hipEventRecord(e); hipEventSynchronize(e); float ms; hipEventElapsedTime(&ms, s, e); if (ms < best) best = ms; sum += ms; }
+            printf("%-56s best %.3f ms %.0f GB/s | mean %.3f ms %.0f GB/s\n", name, best, b2 / best / 1e6, sum / 10, b2 / (sum / 10) / 1e6);
+        };
+        const size_t bn = (size_t)64 * tpi * 17280, bd = (size_t)64 * tpi * 24480;
+        time4([&] { stream_e<1080, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 17 280 B tiles, 3 WG/CU, one list of 768", bn);
+        time4([&] { stream_e<1080, 4><<<dim3(1024, 1), 256>>>(src, 64 * tpi, 1024, out); }, "E: 17 280 B tiles, 4 WG/CU, one list of 1024", bn);
+        time4([&] { stream_f<720, 3><<<dim3(768, 1), 256>>>((const unsigned char *)src, 64 * tpi, 768, out); }, "F: 17 280 B (16+8) items, 3 WG/CU, list of 768", bn);
+        time4([&] { stream_f<720, 4><<<dim3(1024, 1), 256>>>((const unsigned char *)src, 64 * tpi, 1024, out); }, "F: 17 280 B (16+8) items, 4 WG/CU, list of 1024", bn);
+        time4([&] { stream_f<720, 5><<<dim3(1280, 1), 256>>>((const unsigned char *)src, 64 * tpi, 1280, out); }, "F: 17 280 B (16+8) items, 5 WG/CU, list of 1280", bn);
+        time4([&] { stream_e<1530, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 24 480 B tiles, 3 WG/CU, one list of 768", bd);
+        time4([&] { stream_f<1020, 3><<<dim3(768, 1), 256>>>((const unsigned char *)src, 64 * tpi, 768, out); }, "F: 24 480 B (16+8) items, 3 WG/CU, list of 768", bd);
+        time4([&] { stream_f<1020, 4><<<dim3(1024, 1), 256>>>((const unsigned char *)src, 64 * tpi, 1024, out); }, "F: 24 480 B (16+8) items, 4 WG/CU, list of 1024", bd);
+        // the same base tiles INSIDE 23 040-byte tiles (the 5 760 bytes of top nibbles behind every base tile skipped): does HBM
+        // serve 17 280 of every 23 040 bytes as fast as one contiguous run?
+        time4([&] { stream_f<720, 3, 23040><<<dim3(768, 1), 256>>>((const unsigned char *)src, 64 * tpi, 768, out); }, "G: 17 280 of every 23 040 B, 3 WG/CU, list of 768", bn);
+        time4([&] { stream_f<720, 4, 23040><<<dim3(1024, 1), 256>>>((const unsigned char *)src, 64 * tpi, 1024, out); }, "G: 17 280 of every 23 040 B, 4 WG/CU, list of 1024", bn);
+        time4([&] { stream_f<1020, 3, 32640><<<dim3(768, 1), 256>>>((const unsigned char *)src, 64 * tpi, 768, out); }, "G: 24 480 of every 32 640 B, 3 WG/CU, list of 768", bd);
+        time4([&] { stream_e<1440, 3><<<dim3(768, 1), 256>>>(src, 64 * tpi, 768, out); }, "E: 23 040 B tiles (today), 3 WG/CU, list of 768", (size_t)64 * tpi * 23040);
     }
     return 0;
 }
