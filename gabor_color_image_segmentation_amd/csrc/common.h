@@ -56,8 +56,10 @@ static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles o
 // SPLIT slab (round 6: banks of at most two levels with D <= 79, i.e. every 4x6-style bank). SPEC.md §3 allows g <= 46 163, but
 // values of 4096 and more are 5.6e-5 of what BSD500 produces and 2e-7 of the synthetic bench batch (tools/design/
 // narrow_slab_study.py, profiles/r6_notes.md), while every Lloyd pass streamed 16 bits for each. A value is therefore stored
-// as three pieces in three planar arrays per image, all in the tile / plane / slot order above (a tile = S slots, level L
-// starting at slot sl0[L]):
+// as three pieces in three planar arrays per image, tile-major and plane-major as above (a tile = S slots, level L starting at
+// slot sl0[L]), but with the slots of a plane in (slot row, block in tile, slot column) order - a tile's level-0 plane is the
+// raster of its 8 x 32 pixels -: the Gabor kernel's wave then stores 4 rows x 4 blocks x 8 pixels of a plane as ONE run of 128
+// low bytes / 64 nibble bytes (block-major slots made those stores 32- and 16-byte pieces: the stage took 0.71 instead of 0.42 ms):
 //     LO   [ntiles][S]      the low byte, XOR 0x80 (the signed low MFMA digit)
 //     MID  [ntiles][S / 2]  bits 8..11, two slots per byte
 //     TOP  [ntiles][S / 2]  bits 12..15, two slots per byte
@@ -95,7 +97,12 @@ struct GcsLayout {
 
 // Which banks take the split slab: those whose Lloyd pass is kmeans_pass_mfma_kernel's narrow bucket and whose Gabor stores are
 // the level-0 / level-1 paths.
+// (-DGCS_NO_SPLIT: every bank on the wide slab, for same-box A/B runs against the rounds 2-5 format)
+#ifdef GCS_NO_SPLIT
+static inline bool gcs_split_bank(int, int) { return false; }
+#else
 static inline bool gcs_split_bank(int n_levels, int D) { return n_levels <= 2 && D < 80; }
+#endif
 
 // Tiles per image when no edge strip is packed: an upper bound of every bank's tile count for the shape (sizes that
 // must not depend on the bank: partial-sum rows per image).
@@ -235,8 +242,8 @@ __host__ __device__ __forceinline__ unsigned gcs_split_slot(const GcsLayout &lo,
     int blk, iy, ix;
     gcs_locate(lo, y, x, blk, iy, ix);
     const int side = 8 >> L, npl = KP_TP >> (2 * L);
-    return (unsigned)(blk >> 2) * (unsigned)lo.S + (unsigned)(lo.sl0[L] + (r - lo.row0[L]) * npl + (blk & 3) * side * side +
-                                                              (iy >> L) * side + (ix >> L));
+    return (unsigned)(blk >> 2) * (unsigned)lo.S + (unsigned)(lo.sl0[L] + (r - lo.row0[L]) * npl + (iy >> L) * 4 * side +
+                                                              (blk & 3) * side + (ix >> L));
 }
 // byte (relative to the MID / TOP array) and bit shift of a slot's nibble: group of g = max(2, 8 >> L) slots, see above
 __host__ __device__ __forceinline__ void gcs_split_nibble(int L, unsigned slot, unsigned &byte, int &shift) {

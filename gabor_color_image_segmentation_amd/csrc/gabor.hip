@@ -582,17 +582,18 @@ __global__ __launch_bounds__(256, GCS_GABOR_WAVES) void gabor_mfma_kernel(
             if constexpr (SPLIT) {
               if (oy < HL && ox < pitchL) {
                 // Split slab: the lane's 8 pixels are 8 consecutive SLOTS of one block row (level 0) or 4 + 4 slots of one parent
-                // row of two neighbouring blocks (level 1). Per filter: the low bytes (XOR 0x80) go to LO at the slot index, the
+                // row of two neighbouring blocks (level 1: consecutive too when both blocks lie in one tile). Per filter: the low bytes (XOR 0x80) go to LO at the slot index, the
                 // nibbles 8..11 / 12..15 of slots i and i + g / 2 of the group share byte i of MID / TOP at half the slot index.
                 const int by = oy >> ssh, iy = oy & ((1 << ssh) - 1);
                 const int bx0 = ox >> ssh;
                 unsigned char *img = feats + (size_t)b * S.img_bytes;
                 const unsigned pl0 = (unsigned)(offL + (st_c * FLv + fbase) * nplc);          // first slot of the launch's first plane of channel st_c
                 unsigned char *lo_base = img + pl0, *mid_base = img + S.mid_off + (pl0 >> 1), *top_base = img + S.top_off + (pl0 >> 1);
-                const unsigned row_slot = (unsigned)((iy << ssh) + h * nplc);
+                // slot order inside a plane: (slot row, block in tile, slot column): the wave's 4 rows x 4 blocks are one run
+                const unsigned row_slot = (unsigned)((iy << (ssh + 2)) + h * nplc);
                 auto lane_slot = [&](int p) -> unsigned {
                     const int blk = by * S.bx_n + bx0 + p;
-                    return (unsigned)(blk >> 2) * (unsigned)S.S + (unsigned)((blk & 3) << (2 * ssh)) + row_slot;
+                    return (unsigned)(blk >> 2) * (unsigned)S.S + (unsigned)((blk & 3) << ssh) + row_slot;
                 };
                 auto planes = [&](auto &&put) {
 #pragma unroll

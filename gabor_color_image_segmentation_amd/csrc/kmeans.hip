@@ -264,6 +264,11 @@ constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 2
 #ifndef GCS_KP_WAVES
 #define GCS_KP_WAVES 3
 #endif
+// Ablation builds of kmeans_pass_mfma_kernel for same-box A/B runs (tools/build_variant.sh x -DGCS_ABL=n, tools/ab.py; results are
+// WRONG by construction): bit 0 = no assign phase, bit 1 = no update phase, bit 2 = the split slab's items go to LDS as loaded (no unpack).
+#ifndef GCS_ABL
+#define GCS_ABL 0
+#endif
 // DSTEPS = assign K-steps (16 planes = 32 byte-features each); LDS holds ROWS = 16*DSTEPS plane rows (>= D + 1:
 // the spare row D is the count row); the update has NT = 2*DSTEPS N-tiles (8 planes = 16 byte-planes each).
 // NST = 16-byte staging chunks per thread >= ceil(tile_bytes / 4096); surplus chunks re-copy the tile's last chunk.
@@ -393,9 +398,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     __syncthreads();                                   // scratch reads done: the tile buffer is free again
     // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
     if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
-    v4i accu[NT_OWN];
+    // UPD2 (round 6, the split narrow pass with k <= 8): the update's MFMA rows are (cluster j, byte b), its K slots (pixel, byte) and
+    // its columns 16 PLANES - sums[(j, b)][plane] = sel[(j, b)][(px, t)] * X[(px, t)][plane] with sel = the one-hot digit where t == b -,
+    // so that the B operand is a plane row AS IT LIES in LDS (8 pixels x (lo, hi) = one 16-byte read, no byte de-interleave: 40 v_perm
+    // per tile and wave less) and 80 plane rows are 5 accumulator tiles instead of 10 (the deep-bank pass's form, kmeans_pass_native_kernel).
+    constexpr bool UPD2 = SPLIT && KT == 1 && WAVES == 4;
+    constexpr int NACC = UPD2 ? DSTEPS : NT_OWN;
+    v4i accu[NACC];
 #pragma unroll
-    for (int nt = 0; nt < NT_OWN; ++nt) accu[nt] = v4i{0, 0, 0, 0};
+    for (int nt = 0; nt < NACC; ++nt) accu[nt] = v4i{0, 0, 0, 0};
 
     // ---- staging: the tile is ONE contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
     //      ci = tid + 256*i is 16 bytes at byte 16*ci:
@@ -412,6 +423,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     const int nchunk = SPLIT ? lo.S >> 4 : lo.tile_bytes >> 4;   // (split slab: items per tile)
     v4i st[NST];
     v2i sm[NST], stt[NST];                             // split slab: MID and TOP nibbles of the item
+#pragma unroll
+    for (int i = 0; i < NST; ++i) stt[i] = v2i{0, 0};
     int sdst[NST], ssrc[NST];
     int scls[NST];                                     // wave-uniform: 0 = every lane copies, 1 = every lane replicates, 2 = mixed
     bool sl1[NST];
@@ -422,9 +435,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         const int c1 = ci - n0;
         const bool l1 = SPLIT ? c1 >= 0 : c1 >= 0 && c1 < n1;
         sl1[i] = l1;
-        if constexpr (SPLIT)   // level-0 item: 16 pixels of plane row ci >> 4; level-1 item: block c1 & 3 of plane c1 >> 2 (128 bytes of its row)
-            sdst[i] = l1 ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 128]
-                         : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (ci & 15) * 32];
+        if constexpr (SPLIT)
+            // slots of a plane come in (row, block, column) order (csrc/common.h). Level-0 item: row (ci & 15) >> 1 of blocks
+            // 2 (ci & 1), 2 (ci & 1) + 1 of plane ci >> 4: two 16-byte pieces 128 bytes apart. Level-1 item: parent row c1 & 3 of
+            // the four blocks of plane c1 >> 2: per block 4 parents = fine rows 2 p, 2 p + 1 = 32 bytes at q * 128 + 32 p.
+            sdst[i] = l1 ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 32]
+                         : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (ci & 1) * 256 + ((ci & 15) >> 1) * 16];
         else
             sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
                       : l1    ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 3)) * KP_PITCH + (c1 & 7) * 64]
@@ -451,10 +467,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const v2i *pt = reinterpret_cast<const v2i *>(ib + lo.top_off + (size_t)tn * (lo.S >> 1));
 #pragma unroll
             for (int i = 0; i < NST; ++i) stt[i] = kp_load(&pt[ssrc[i]], nt_loads);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NST; ++i) stt[i] = v2i{0, 0};
-        }
+        }                                  // (no TOP run: stage_write's unpack does not read stt then)
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     // a level-1 chunk of the LDS image: coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice,
@@ -483,9 +496,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         *reinterpret_cast<lds_v4i_ptr>(dst + 32 - f32 + 16 - e16) = rb;
     };
     // split slab: the high bytes (XOR 0x80) of the first and the second half of a nibble group from its MID and TOP dwords
+    // (`top_regs`: the tile in the staging registers brought its TOP nibbles - uniform; without them three instructions do)
+    bool top_regs = false;
     auto split_hi = [&](unsigned mid, unsigned top, unsigned &e, unsigned &o) {
-        e = ((mid & 0x0f0f0f0fu) | ((top << 4) & 0xf0f0f0f0u)) ^ 0x80808080u;
-        o = (((mid >> 4) & 0x0f0f0f0fu) | (top & 0xf0f0f0f0u)) ^ 0x80808080u;
+        if (top_regs) {
+            e = ((mid & 0x0f0f0f0fu) | ((top << 4) & 0xf0f0f0f0u)) ^ 0x80808080u;
+            o = (((mid >> 4) & 0x0f0f0f0fu) | (top & 0xf0f0f0f0u)) ^ 0x80808080u;
+        } else {
+            e = (mid & 0x0f0f0f0fu) | 0x80808080u;
+            o = ((mid >> 4) & 0x0f0f0f0fu) | 0x80808080u;
+        }
     };
     auto stage_write = [&]() {
 #pragma unroll
@@ -494,7 +514,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             if constexpr (SPLIT) {
                 const v2i m = sm[i], t = stt[i];
                 auto level0 = [&]() {
-                    // two groups of 8 pixels: low bytes (a, b), high bytes e (pixels 0..3) and o (pixels 4..7) -> u16 pairs
+                    // two groups of 8 pixels (the row of two neighbouring blocks): low bytes (a, b), high bytes e (pixels 0..3)
+                    // and o (pixels 4..7) -> u16 pairs
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         unsigned e, o;
@@ -505,24 +526,40 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                         w[1] = (int)__builtin_amdgcn_perm(e, a, 0x07030602u);
                         w[2] = (int)__builtin_amdgcn_perm(o, bb, 0x05010400u);
                         w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
-                        *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 16 * g) = w;
+                        *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 128 * g) = w;
                     }
                 };
                 auto level1 = [&]() {
-                    // two halves of the block's 4 x 4 parents: parent rows (2 hh, 2 hh + 1), a nibble group = one parent row
+                    // one parent row of the tile's four blocks: block q's four parents are v[q] (low bytes) and two bytes of m / t
+                    // (a nibble group = one parent row of one block); every parent twice, into the fine rows 2 p and 2 p + 1.
+                    // Eight consecutive lanes are the four parent rows of two planes (576 bytes apart = 64 modulo 128): the
+                    // odd plane's lanes write their two identical pieces in the other order, so that a ds_write_b128 group
+                    // covers eight distinct 16-byte columns.
+                    const int e16 = ((lane >> 2) & 1) * 16;
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        unsigned e, o;                                   // e = (r0 p0, r0 p1, r1 p0, r1 p1), o = (r0 p2, r0 p3, r1 p2, r1 p3)
-                        split_hi((unsigned)m[hh], (unsigned)t[hh], e, o);
-                        const unsigned a = (unsigned)v[2 * hh], bb = (unsigned)v[2 * hh + 1];
-                        v4i w;
-                        w[0] = (int)__builtin_amdgcn_perm(e, a, 0x05010400u);
-                        w[1] = (int)__builtin_amdgcn_perm(o, a, 0x05030402u);
-                        w[2] = (int)__builtin_amdgcn_perm(e, bb, 0x07010600u);
-                        w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
-                        replicate_write(sdst[i] + 64 * hh, w);
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned e, o;                                   // e = (A p0, A p1, B p0, B p1), o = (A p2, A p3, B p2, B p3)
+                        split_hi((unsigned)m[j], (unsigned)t[j], e, o);
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const unsigned a = (unsigned)v[2 * j + qq];
+                            const unsigned w0 = __builtin_amdgcn_perm(e, a, qq ? 0x07010600u : 0x05010400u);   // parents 0, 1
+                            const unsigned w1 = __builtin_amdgcn_perm(o, a, qq ? 0x07030602u : 0x05030402u);   // parents 2, 3
+                            v4i w;
+                            w[0] = (int)__builtin_amdgcn_perm(0u, w0, 0x01000100u);
+                            w[1] = (int)__builtin_amdgcn_perm(0u, w0, 0x03020302u);
+                            w[2] = (int)__builtin_amdgcn_perm(0u, w1, 0x01000100u);
+                            w[3] = (int)__builtin_amdgcn_perm(0u, w1, 0x03020302u);
+                            const int d = sdst[i] + 128 * (2 * j + qq);
+                            *reinterpret_cast<lds_v4i_ptr>(d + e16) = w;
+                            *reinterpret_cast<lds_v4i_ptr>(d + 16 - e16) = w;
+                        }
                     }
                 };
+                if (GCS_ABL & 4) {
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 128) = v4i{m[0], m[1], t[0], t[1]};
+                } else
                 if (scls[i] == 0) level0();
                 else if (scls[i] == 1) level1();
                 else if (sl1[i]) level1();
@@ -587,6 +624,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         by = blk0 / lo.bx_n;
         bx = blk0 - by * lo.bx_n;
     }
+    if constexpr (SPLIT) {                 // wave-uniform: in SGPRs, advanced on the scalar unit (the wide kernels' register
+        by = __builtin_amdgcn_readfirstlane(by);   // allocation was tuned with them in VGPRs: left alone)
+        bx = __builtin_amdgcn_readfirstlane(bx);
+    }
     // split slab: (image of the list, tile inside it) of the tile that is LOADED next - one step ahead of `tin` -, advanced like
     // `tin`: s1 tiles on / back modulo the image, qG (+ 1 on a wrap) images on / back; and the iteration whose flag that load needs
     const int qG = __builtin_amdgcn_readfirstlane(G / ntiles);
@@ -595,7 +636,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         return __builtin_amdgcn_readfirstlane(it < KP_FLAGS ? (int)s_flag[it < KP_FLAGS ? it : 0] : 1) != 0;
     };
     auto load_next_split = [&]() {
-        stage_load_split(bimg_l, tin_l, tile_has_top(it_l));
+        top_regs = tile_has_top(it_l);
+        stage_load_split(bimg_l, tin_l, top_regs);
         const int tn = reverse ? tin_l - s1 : tin_l + s1;
         const bool wrap = reverse ? tn < 0 : tn >= ntiles;
         tin_l = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
@@ -625,7 +667,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         const int blk = 4 * tin + wave;                          // block index inside the image
         // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
 #pragma unroll
-        for (int sub_i = 0; sub_i < (WAVES == 8 ? 1 : 2); ++sub_i) {
+        for (int sub_i = 0; sub_i < ((GCS_ABL & 1) ? 0 : WAVES == 8 ? 1 : 2); ++sub_i) {
             const int sub = WAVES == 8 ? half : sub_i;
             const int n = lane & 31, h = lane >> 5;
             const int pl = wave * 64 + sub * 32 + n;
@@ -710,7 +752,32 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         }
         if (WAVES == 8 && do_acc) __syncthreads();             // the block's labels come from two waves
         // -------- update: one-hot MFMA over the block's 64 pixels
-        if (do_acc) {
+        if constexpr (UPD2) {
+          if (do_acc && !(GCS_ABL & 2)) {
+            // lane (row r = un = (j, b), K group ug): pixels 8 ug .. 8 ug + 7 of the block's 32-pixel half hf
+            const unsigned eqj = (unsigned)(un >> 1) * 0x01010101u;
+            const unsigned sel01 = (un & 1) ? 0x010c000cu : 0x0c010c00u, sel23 = (un & 1) ? 0x030c020cu : 0x0c030c02u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const v2i lw = *reinterpret_cast<const v2i *>(&s_lab[wave * 64 + hf * 32 + 8 * ug]);
+                v4i oh;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned x = (unsigned)lw[i] ^ eqj;                    // byte == 0 <=> label == j
+                    const unsigned y = (x | 0x80808080u) - 0x01010101u;        // top bit clear <=> byte == 0
+                    const unsigned d = ~y & 0x80808080u;                        // digit -128 where label == j
+                    oh[2 * i] = (int)__builtin_amdgcn_perm(0u, d, sel01);       // (px, t): the digit where t == b, 0 elsewhere
+                    oh[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, d, sel23);
+                }
+#pragma unroll
+                for (int pt = 0; pt < DSTEPS; ++pt) {
+                    const v4i bx_ = *reinterpret_cast<const v4i *>(&s_tile[(16 * pt + un) * KP_PITCH + (wave * 64 + hf * 32 + 8 * ug) * 2]);
+                    accu[pt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[pt], 0, 0, 0);
+                }
+            }
+          }
+        } else
+        if (do_acc && !(GCS_ABL & 2)) {
             const v4i lw = *reinterpret_cast<const v4i *>(&s_lab[wave * 64 + 16 * ug]);
             v4i oh;
 #pragma unroll
@@ -753,6 +820,39 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     }
 
     if (!do_acc) return;
+    if constexpr (UPD2) {
+        // ---- fold (UPD2): rows = (cluster, byte), columns = planes
+        constexpr int RW2 = 16 * DSTEPS;                      // planes per row
+        int *red = reinterpret_cast<int *>(s_tile);           // [4 blocks of the tile][16 rows][RW2]
+        static_assert(4 * 16 * RW2 * 4 <= KP_ROWS * KP_PITCH, "fold buffer exceeds the tile buffer");
+#pragma unroll
+        for (int pt = 0; pt < DSTEPS; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * ug + e) * RW2 + 16 * pt + un] = accu[pt][e];
+        __syncthreads();
+        const int D1 = D + 1;
+        auto folded = [&](int j, int bb, int plane) {
+            int sm_ = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sm_ += red[(w * 16 + 2 * j + bb) * RW2 + plane];
+            return -(long long)sm_ / 128;                     // the one-hot digit is -128
+        };
+        for (int i = tid; i < K * D1; i += NTHR) {
+            const int j = i / D1, e = i % D1;                 // e = LOGICAL feature (or D = the count)
+            const long long nj = folded(j, 0, D);             // the count row reads +1 in both bytes
+            long long out = nj;
+            if (e < D) {
+                const int c = e / lo.F, f = e - c * lo.F;       // physical plane of logical feature e (levels unrolled)
+                int pe = kp_plane_on_level<0>(lo, c, f);
+                { const int q = kp_plane_on_level<1>(lo, c, f); pe = q >= 0 ? q : pe; }
+                { const int q = kp_plane_on_level<2>(lo, c, f); pe = q >= 0 ? q : pe; }
+                { const int q = kp_plane_on_level<3>(lo, c, f); pe = q >= 0 ? q : pe; }
+                out = (folded(j, 0, pe) + 128 * nj) + 256 * (folded(j, 1, pe) + 128 * nj);
+            }
+            partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = (uint64_t)out;
+        }
+    }
+    if constexpr (!UPD2) {
     // ---- fold the four waves' accumulators (rows = clusters, cols = byte-planes) and emit the row: every wave
     //      parks its registers in its own slice of the tile buffer (no zero-fill, no atomics), one barrier.
     constexpr int RW = KP_NT * 16;                            // byte-planes per cluster row
@@ -786,6 +886,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             out = (folded(j, 2 * pe) + 128 * nj) + 256 * (folded(j, 2 * pe + 1) + 128 * nj);
         }
         partials[partial_index(per_image, b, part, parts, (int)gridDim.y, i, K * D1)] = (uint64_t)out;
+    }
     }
 }
 
@@ -875,7 +976,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     constexpr int PART_O = TILE_B, APAT_O = PART_O + 4 * NV_PART_W * 8, LAB_O = APAT_O + NL * NV_KS * NV_APAT_SLOTS * 16;
     constexpr int CONST_O = LAB_O + KP_TP, NJ_O = CONST_O + 16 * 8, LDS_B = NJ_O + 16 * 8;
     static_assert(MINB * ((LDS_B + 1279) / 1280) <= 128, "LDS: gfx950 allocates 160 KB in 1280-byte granules");
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_B];
+    __shared__ __attribute__((aligned(64))) unsigned char s_mem[LDS_B];   // (stage_write XORs bits 4-5 of full level-0 addresses: the base must be a multiple of 64)
     unsigned char *const s_tile = s_mem;
     v4i *const s_apat = reinterpret_cast<v4i *>(s_mem + APAT_O);             // [level][K-step][slot]
     unsigned char *const s_lab = s_mem + LAB_O;

@@ -647,14 +647,14 @@ extern "C" int gcs_score_batch_resident(const int32_t *labels, const void *truth
         return gcs_fail(GCS_EINVAL, "gcs_score_batch_resident: NULL pointer");
     if (B <= 0 || B > 65535 || T <= 0 || B + T > 1000000 || max_annotators <= 0 || H <= 0 || W <= 0 ||
         (long long)H * W > 0x7fffffffLL || n_segments <= 0 || n_truth_labels <= 0 || (truth_is_u8 && n_truth_labels > 256) ||
-        (long long)T * n_segments * n_truth_labels > 0x3fffffffLL)
+        (long long)T * n_segments * n_truth_labels > 0x3fffffffLL || (long long)B * n_segments > 0x3fffffffLL)
         return gcs_fail(GCS_EINVAL, "gcs_score_batch_resident: bad shape");
     const int words = H * bits_wp(W);
     const long long nw = (long long)B * words;
     ZeroList z;
     z.p[0] = hist; z.n[0] = (unsigned)((size_t)T * n_segments * n_truth_labels);
-    z.p[1] = area; z.n[1] = (unsigned)(B * n_segments);
-    z.p[2] = perim; z.n[2] = (unsigned)(B * n_segments);
+    z.p[1] = area; z.n[1] = (unsigned)((size_t)B * n_segments);       // (B * n_segments < 2^30: checked above)
+    z.p[2] = perim; z.n[2] = (unsigned)((size_t)B * n_segments);
     z.p[3] = reinterpret_cast<unsigned *>(seg_max); z.n[3] = (unsigned)B;
     hipLaunchKernelGGL(zero_kernel, dim3(grid_for((long long)z.n[0], 256, 1024)), dim3(256), 0, stream, z);
     GCS_CHECK_LAUNCH("gcs_score_batch_resident(zero)");

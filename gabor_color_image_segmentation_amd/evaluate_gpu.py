@@ -242,27 +242,40 @@ class DeviceTruth:
             self.first_d = torch.from_numpy(self.first).to(dev)
             self.img_of_d = torch.from_numpy(self.img_of).to(dev)
             torch.cuda.current_stream(dev).synchronize()       # t16 may go (uint8 case): the kernels that read it are done
-        self._out = {}                                         # per n_seg: (device result block, pinned host block, views)
+        self._out = None                                       # (capacity, device result block, pinned host block, views, ...)
+        self._scratch = None
 
     def _buffers(self, n_seg):
         """ONE device block for everything a call returns (counts | under | under_np | seg_max | area | perim) and its pinned
         mirror: one device-to-host copy of a few KB and one synchronisation per call instead of five; the contingency tables
-        stay on the device (gcs_region_reduce takes the two sums metrics.py:128-140 needs out of them)."""
+        stay on the device (gcs_region_reduce takes the two sums metrics.py:128-140 needs out of them).
+
+        ONE entry per DeviceTruth, sized to a CAPACITY of segments (the next power of two, at least 8): a data-set loop over
+        connected-region maps, whose label count differs from batch to batch, reuses it and reallocates - dropping the old
+        blocks - only when a batch needs more (the kernels take the capacity as their table stride; segments that do not occur
+        have area 0 and perimeter 0 and add nothing to any score). Returns (capacity, device block, pinned block, offsets,
+        bit-plane scratch, contingency tables)."""
         import torch
-        ent = self._out.get(n_seg)
-        if ent is None:
+        cap = 8                                                 # (k-means maps of the default k stay at their exact size)
+        while cap < n_seg:
+            cap *= 2
+        if self._scratch is None:                               # the label maps' bit planes: does not depend on n_seg
+            self._scratch = torch.empty(_lib.load().gcs_bit_planes_bytes(self.b, self.h, self.w), dtype=torch.uint8,
+                                        device=self.device)
+        ent = self._out
+        if ent is None or ent[0] < cap:
+            self._out = ent = None                              # the old blocks go back to the allocator first
             b, t = self.b, self.t
             sizes = [("counts", (b + 3 * t) * 8), ("under", t * 8), ("under_np", t * 8), ("seg_max", b * 4),
-                     ("area", b * n_seg * 4), ("perim", b * n_seg * 4)]
+                     ("area", b * cap * 4), ("perim", b * cap * 4)]
             offs, o = {}, 0
             for name, nbytes in sizes:
                 offs[name] = (o, nbytes)
                 o += (nbytes + 15) // 16 * 16
             dev_blk = torch.empty(o, dtype=torch.uint8, device=self.device)
             host_blk = torch.empty(o, dtype=torch.uint8, pin_memory=True)
-            scratch = torch.empty(_lib.load().gcs_bit_planes_bytes(b, self.h, self.w), dtype=torch.uint8, device=self.device)
-            hist = torch.empty(t * n_seg * self.stride, dtype=torch.int32, device=self.device)     # never leaves the device
-            ent = self._out[n_seg] = (dev_blk, host_blk, offs, scratch, hist)
+            hist = torch.empty(t * cap * self.stride, dtype=torch.int32, device=self.device)       # never leaves the device
+            ent = self._out = (cap, dev_blk, host_blk, offs, self._scratch, hist)
         return ent
 
 
@@ -301,11 +314,11 @@ class _PendingScores:
     reference's float arithmetic. Submitting the next batch before collecting this one lets its kernels run under that
     arithmetic (``all_scores_batch_resident`` = submit + result)."""
 
-    def __init__(self, truth, b, h, w, n_seg, host_blk, offs, event):
-        self._a = (truth, b, h, w, n_seg, host_blk, offs, event)
+    def __init__(self, truth, b, h, w, n_seg, host_blk, offs, event, cap=None):
+        self._a = (truth, b, h, w, n_seg, host_blk, offs, event, cap or n_seg)
 
     def result(self) -> list:
-        truth, b, h, w, n_seg, host_blk, offs, event = self._a
+        truth, b, h, w, n_seg, host_blk, offs, event, cap = self._a
         event.synchronize()
         raw = host_blk.numpy()
         view = lambda k, dt: raw[offs[k][0]:offs[k][0] + offs[k][1]].view(dt)
@@ -313,8 +326,8 @@ class _PendingScores:
         seg_max = view("seg_max", np.int32)
         if int(seg_max.max()) >= n_seg:
             raise ValueError(f"a label map holds label {int(seg_max.max())} but n_segments = {n_seg}")
-        area = view("area", np.int32).reshape(b, n_seg)
-        perim = view("perim", np.int32).reshape(b, n_seg)
+        area = view("area", np.int32).reshape(b, cap)[:, :n_seg]     # tables are laid out at the capacity; columns >= n_seg are zero
+        perim = view("perim", np.int32).reshape(b, cap)[:, :n_seg]
         reg = _region_scores_batch(view("under", np.uint64), view("under_np", np.uint64), area, perim, truth.first, h, w)
         out = []
         cf = counts.astype(np.float64).tolist()                      # counts < 2^53: exact; Python floats from here on
@@ -340,7 +353,7 @@ class _PendingScores:
 
 def submit_scores_batch_resident(labels, truth: DeviceTruth, n_segments=None) -> _PendingScores:
     """Enqueue the scoring of a (B,H,W) int32 device label batch against resident ground truth; ``.result()`` returns what
-    ``all_scores_batch_device`` returns. One result block per (truth, n_segments): collect a submission before submitting the
+    ``all_scores_batch_device`` returns. One result block per DeviceTruth: collect a submission before submitting the
     next batch against the SAME DeviceTruth."""
     import torch
     lib = _lib.load()
@@ -351,21 +364,21 @@ def submit_scores_batch_resident(labels, truth: DeviceTruth, n_segments=None) ->
         raise ValueError("label batch does not match the resident truth (images, shape or device)")
     labels = labels.contiguous()
     n_seg = int(n_segments) if n_segments is not None else int(labels.max().item()) + 1
-    dev_blk, host_blk, offs, scratch, hist_d = truth._buffers(n_seg)
+    cap, dev_blk, host_blk, offs, scratch, hist_d = truth._buffers(n_seg)
     base = dev_blk.data_ptr()
     ptr = {k: base + o for k, (o, _) in offs.items()}
     with torch.cuda.device(truth.device):
         stream = torch.cuda.current_stream(truth.device)
         _lib.check(lib.gcs_score_batch_resident(labels.data_ptr(), truth.planes.data_ptr(), truth.bd_counts.data_ptr(),
                                                 truth.maps.data_ptr(), 1 if truth.u8 else 0, truth.first_d.data_ptr(),
-                                                truth.img_of_d.data_ptr(), b, truth.t, truth.a_max, h, w, n_seg, truth.stride,
+                                                truth.img_of_d.data_ptr(), b, truth.t, truth.a_max, h, w, cap, truth.stride,
                                                 scratch.data_ptr(), hist_d.data_ptr(), ptr["counts"], ptr["seg_max"], ptr["area"],
                                                 ptr["perim"], ptr["under"], ptr["under_np"], stream.cuda_stream),
                    "gcs_score_batch_resident")
         host_blk.copy_(dev_blk, non_blocking=True)
         event = torch.cuda.Event()
         event.record(stream)
-    return _PendingScores(truth, b, h, w, n_seg, host_blk, offs, event)
+    return _PendingScores(truth, b, h, w, n_seg, host_blk, offs, event, cap)
 
 
 def all_scores_batch_resident(labels, truth: DeviceTruth, n_segments=None) -> list:

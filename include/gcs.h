@@ -199,9 +199,10 @@ int gcs_boundary_counts_batch(const int32_t *labels_dev, const uint16_t *truth_d
  * find_boundaries(truth) for every image it scores and groundtruth.py:44-48 rescans the directories per id. gcs_truth_prepare
  * does that work ONCE per annotator map: truth_dev uint16 [T][H][W] -> planes_dev, gcs_bit_planes_bytes(T, H, W) bytes of BIT
  * planes (rows of 64-bit words, bit i of word w = pixel 64 w + i; all thick-boundary planes bd(T_t), then all 5x5-dilated planes),
- * bd_counts_dev uint64 [T] = sum bd(T_t) (the recall denominators, metrics.py:72), and - when truth8_dev is not NULL and every
- * label is below 256 (BSD500: at most 208) - the maps narrowed to uint8 [T][H][W] for gcs_region_counts_batch_u8. The caller
- * keeps all of it on the device for as long as it scores images of these ids. */
+ * bd_counts_dev uint64 [T] = sum bd(T_t) (the recall denominators, metrics.py:72), and - when truth8_dev is not NULL - the maps
+ * narrowed to uint8 [T][H][W] for gcs_region_counts_batch_u8. The CALLER guarantees that every annotator label is below 256 when
+ * it passes truth8_dev (BSD500: at most 208; the narrowing keeps the low byte and does not check: evaluate_gpu.DeviceTruth does).
+ * The caller keeps all of it on the device for as long as it scores images of these ids. */
 size_t gcs_bit_planes_bytes(int M, int H, int W);
 int gcs_truth_prepare(const uint16_t *truth_dev, int T, int H, int W, void *planes_dev, uint64_t *bd_counts_dev,
                       uint8_t *truth8_dev, gcs_stream_t stream);

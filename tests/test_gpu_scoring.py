@@ -210,7 +210,7 @@ def test_resident_truth_bit_planes_equal_scipy(built):
 
 
 def test_the_fused_resident_scorer_equals_its_three_parts(built):
-    """gcs_score_batch_resident (five launches: one zeroing launch, label planes dilated inline) against the three entry points it
+    """gcs_score_batch_resident (six launches: zero | label bit planes + maxima | their dilation | boundary counts | region tables | their reduction) against the three entry points it
     fuses - gcs_boundary_counts_resident (dilated label planes from their own launch), gcs_region_counts_batch_u8 and
     gcs_region_reduce - and gcs_region_reduce against NumPy on the tables: every output word equal."""
     import torch
