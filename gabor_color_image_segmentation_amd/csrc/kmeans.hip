@@ -453,53 +453,36 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 #pragma unroll
         for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[ssrc[i]], nt_loads);
     };
-    // split slab: tile `tn` of image `bi` of the list; the TOP nibbles only when the tile's flag word is set (they are zero otherwise)
-    auto stage_load_split = [&](int bi, int tn, bool top) {
-        const unsigned char *ib = fb + (size_t)bi * lo.img_bytes;
-        const v4i *pl = reinterpret_cast<const v4i *>(ib + (size_t)tn * lo.S);
-        const v2i *pm = reinterpret_cast<const v2i *>(ib + lo.mid_off + (size_t)tn * (lo.S >> 1));
+    // split slab: the tile whose LO run starts at p_lo and whose MID run at p_mid (uniform pointers; 32-bit lane offsets: the loads
+    // take an SGPR base and need no vector address arithmetic); the TOP run only when the tile's flag word is set
+    auto stage_load_split = [&](const unsigned char *p_lo, const unsigned char *p_mid, bool top) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            st[i] = kp_load(&pl[ssrc[i]], nt_loads);
-            sm[i] = kp_load(&pm[ssrc[i]], nt_loads);
+            const unsigned o = (unsigned)ssrc[i] * 16u;
+            st[i] = kp_load(reinterpret_cast<const v4i *>(p_lo + o), nt_loads);
+            sm[i] = kp_load(reinterpret_cast<const v2i *>(p_mid + (o >> 1)), nt_loads);
         }
         if (top) {
-            const v2i *pt = reinterpret_cast<const v2i *>(ib + lo.top_off + (size_t)tn * (lo.S >> 1));
+            const unsigned char *p_top = p_mid + (lo.top_off - lo.mid_off);
 #pragma unroll
-            for (int i = 0; i < NST; ++i) stt[i] = kp_load(&pt[ssrc[i]], nt_loads);
+            for (int i = 0; i < NST; ++i) stt[i] = kp_load(reinterpret_cast<const v2i *>(p_top + (unsigned)ssrc[i] * 8u), nt_loads);
         }                                  // (no TOP run: stage_write's unpack does not read stt then)
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
-    // a level-1 chunk of the LDS image: coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each pixel twice,
-    // each row into two fine rows = four 16-byte pieces of a 64-byte region at `dst`. Lanes are 64 bytes apart, so piece k
-    // of lanes l and l+2 would share banks (4-way conflicts: SQ_LDS_BANK_CONFLICT 0.4 M -> 17.7 M cycles per
-    // launch when every lane wrote its pieces in the same order). Lanes therefore start on different pieces:
-    // bit 2 of the lane picks which coarse row goes first, bit 1 which of its two pieces; the eight lanes of a
-    // ds_write_b128 group then cover 32 distinct banks.
-    auto replicate_write = [&](int dst, const v4i v) {
-        const bool f = (lane >> 2) & 1;
-        const unsigned x0 = f ? (unsigned)v[2] : (unsigned)v[0], x1 = f ? (unsigned)v[3] : (unsigned)v[1];
-        const unsigned y0 = f ? (unsigned)v[0] : (unsigned)v[2], y1 = f ? (unsigned)v[1] : (unsigned)v[3];
-        v4i ra, rb;
-        ra[0] = (int)__builtin_amdgcn_perm(0u, x0, 0x01000100u);
-        ra[1] = (int)__builtin_amdgcn_perm(0u, x0, 0x03020302u);
-        ra[2] = (int)__builtin_amdgcn_perm(0u, x1, 0x01000100u);
-        ra[3] = (int)__builtin_amdgcn_perm(0u, x1, 0x03020302u);
-        rb[0] = (int)__builtin_amdgcn_perm(0u, y0, 0x01000100u);
-        rb[1] = (int)__builtin_amdgcn_perm(0u, y0, 0x03020302u);
-        rb[2] = (int)__builtin_amdgcn_perm(0u, y1, 0x01000100u);
-        rb[3] = (int)__builtin_amdgcn_perm(0u, y1, 0x03020302u);
-        const int e16 = ((lane >> 1) & 1) * 16, f32 = f ? 32 : 0;
-        *reinterpret_cast<lds_v4i_ptr>(dst + f32 + e16) = ra;
-        *reinterpret_cast<lds_v4i_ptr>(dst + f32 + 16 - e16) = ra;
-        *reinterpret_cast<lds_v4i_ptr>(dst + 32 - f32 + e16) = rb;
-        *reinterpret_cast<lds_v4i_ptr>(dst + 32 - f32 + 16 - e16) = rb;
-    };
+    // (wide slab) a level-1 chunk of the LDS image: coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each
+    // pixel twice, each row into two fine rows = four 16-byte pieces of a 64-byte region. Lanes are 64 bytes apart, so piece k
+    // of lanes l and l+2 would share banks (4-way conflicts: SQ_LDS_BANK_CONFLICT 0.4 M -> 17.7 M cycles per launch when every
+    // lane wrote its pieces in the same order). Lanes therefore start on different pieces: bit 2 of the lane picks which coarse
+    // row goes first, bit 1 which of its two pieces; the eight lanes of a ds_write_b128 group then cover 32 distinct banks.
     // split slab: the high bytes (XOR 0x80) of the first and the second half of a nibble group from its MID and TOP dwords
     // (`top_regs`: the tile in the staging registers brought its TOP nibbles - uniform; without them three instructions do)
     bool top_regs = false;
+    // (TOPP: a compile-time copy of top_regs - ONE branch per tile around two forms of stage_write; tested inside split_hi it
+    //  became four scalar branches per nibble group)
+    auto stage_write_as = [&](auto topp) {
+    constexpr bool TOPP = decltype(topp)::value;
     auto split_hi = [&](unsigned mid, unsigned top, unsigned &e, unsigned &o) {
-        if (top_regs) {
+        if constexpr (TOPP) {
             e = ((mid & 0x0f0f0f0fu) | ((top << 4) & 0xf0f0f0f0u)) ^ 0x80808080u;
             o = (((mid >> 4) & 0x0f0f0f0fu) | (top & 0xf0f0f0f0u)) ^ 0x80808080u;
         } else {
@@ -507,7 +490,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             o = ((mid >> 4) & 0x0f0f0f0fu) | 0x80808080u;
         }
     };
-    auto stage_write = [&]() {
+    {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const v4i v = st[i];
@@ -566,12 +549,36 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 else level0();
             } else if (scls[i] == 0) {
                 *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
-            } else if (scls[i] == 1 || sl1[i]) {
-                replicate_write(sdst[i], v);
-            } else {                                      // a lane of a mixed wave whose chunk is not level 1
-                *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
+            } else {
+                // (the wide slab's level-1 chunk, in the code shape the wide kernels' register allocation was tuned with)
+                const bool f = (lane >> 2) & 1;
+                const unsigned x0 = f ? (unsigned)v[2] : (unsigned)v[0], x1 = f ? (unsigned)v[3] : (unsigned)v[1];
+                const unsigned y0 = f ? (unsigned)v[0] : (unsigned)v[2], y1 = f ? (unsigned)v[1] : (unsigned)v[3];
+                v4i ra, rb;
+                ra[0] = (int)__builtin_amdgcn_perm(0u, x0, 0x01000100u);
+                ra[1] = (int)__builtin_amdgcn_perm(0u, x0, 0x03020302u);
+                ra[2] = (int)__builtin_amdgcn_perm(0u, x1, 0x01000100u);
+                ra[3] = (int)__builtin_amdgcn_perm(0u, x1, 0x03020302u);
+                rb[0] = (int)__builtin_amdgcn_perm(0u, y0, 0x01000100u);
+                rb[1] = (int)__builtin_amdgcn_perm(0u, y0, 0x03020302u);
+                rb[2] = (int)__builtin_amdgcn_perm(0u, y1, 0x01000100u);
+                rb[3] = (int)__builtin_amdgcn_perm(0u, y1, 0x03020302u);
+                if (scls[i] == 1 || sl1[i]) {
+                    const int e16 = ((lane >> 1) & 1) * 16, f32 = f ? 32 : 0;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + e16) = ra;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + f32 + 16 - e16) = ra;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + e16) = rb;
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 32 - f32 + 16 - e16) = rb;
+                } else {                                  // a lane of a mixed wave whose chunk is not level 1
+                    *reinterpret_cast<lds_v4i_ptr>(sdst[i]) = v;
+                }
             }
         }
+    }
+    };
+    auto stage_write = [&]() {
+        if (SPLIT && top_regs) stage_write_as(std::true_type{});
+        else stage_write_as(std::false_type{});
     };
     // Levels >= 2 (deep banks): every group of 8 consecutive pixels of a plane row (one row of one 8x8 block) is the
     // replication of 8 >> L level-L pixels of the compact copy in s_coarse.
@@ -628,34 +635,52 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         by = __builtin_amdgcn_readfirstlane(by);   // allocation was tuned with them in VGPRs: left alone)
         bx = __builtin_amdgcn_readfirstlane(bx);
     }
-    // split slab: (image of the list, tile inside it) of the tile that is LOADED next - one step ahead of `tin` -, advanced like
-    // `tin`: s1 tiles on / back modulo the image, qG (+ 1 on a wrap) images on / back; and the iteration whose flag that load needs
+    // split slab: the tile that is LOADED next - one step ahead of `tin` - as two running pointers (its LO and MID runs) and its
+    // tile index inside its image, advanced like `tin`: s1 tiles on / back modulo the image, qG (+ 1 on a wrap) images on / back -
+    // one of two precomputed 64-bit strides per pointer -, and the iteration whose flag that load needs
     const int qG = __builtin_amdgcn_readfirstlane(G / ntiles);
-    int tin_l = tin, bimg_l = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) / ntiles), it_l = 0;
+    int tin_l = tin, it_l = 0;
+    const unsigned char *p_lo_l = nullptr, *p_mid_l = nullptr;
+    long long d_lo[2] = {0, 0}, d_mid[2] = {0, 0};           // [wrap]
+    if constexpr (SPLIT) {
+        const int bi0 = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) / ntiles);
+        const unsigned char *img = fb + (size_t)bi0 * lo.img_bytes;
+        p_lo_l = img + (size_t)tin * lo.S;
+        p_mid_l = img + lo.mid_off + (size_t)tin * (lo.S >> 1);
+        const long long sg = reverse ? -1 : 1;
+        d_lo[0] = sg * ((long long)qG * lo.img_bytes + (long long)s1 * lo.S);
+        d_lo[1] = sg * ((long long)(qG + 1) * lo.img_bytes + (long long)(s1 - ntiles) * lo.S);
+        d_mid[0] = sg * ((long long)qG * lo.img_bytes + (long long)s1 * (lo.S >> 1));
+        d_mid[1] = sg * ((long long)(qG + 1) * lo.img_bytes + (long long)(s1 - ntiles) * (lo.S >> 1));
+    }
     auto tile_has_top = [&](int it) -> bool {
         return __builtin_amdgcn_readfirstlane(it < KP_FLAGS ? (int)s_flag[it < KP_FLAGS ? it : 0] : 1) != 0;
     };
-    auto load_next_split = [&]() {
-        top_regs = tile_has_top(it_l);
-        stage_load_split(bimg_l, tin_l, top_regs);
+    auto load_next_split = [&](bool top) {
+        top_regs = top;
+        stage_load_split(p_lo_l, p_mid_l, top_regs);
         const int tn = reverse ? tin_l - s1 : tin_l + s1;
         const bool wrap = reverse ? tn < 0 : tn >= ntiles;
         tin_l = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
-        bimg_l += reverse ? -(qG + (wrap ? 1 : 0)) : qG + (wrap ? 1 : 0);
+        p_lo_l += wrap ? d_lo[1] : d_lo[0];
+        p_mid_l += wrap ? d_mid[1] : d_mid[0];
         ++it_l;
     };
     if constexpr (SPLIT) {
-        if (ltile < nlist) load_next_split();
+        if (ltile < nlist) load_next_split(tile_has_top(0));
     }
     for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
+        // (split slab) the flag of the tile loaded in this iteration: read from LDS here, used behind the barrier
+        int flag_next = 1;
+        if constexpr (SPLIT) flag_next = it_l < KP_FLAGS ? (int)s_flag[it_l < KP_FLAGS ? it_l : 0] : 1;
         stage_write();
         __syncthreads();
         // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
         // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
         __builtin_amdgcn_s_setprio(3);
         if (ltile + G < nlist) {                              // in flight during the MFMAs
-            if constexpr (SPLIT) load_next_split();
+            if constexpr (SPLIT) load_next_split(__builtin_amdgcn_readfirstlane(flag_next) != 0);
             else stage_load(phys(ltile + G));
         }
         __builtin_amdgcn_s_setprio(0);

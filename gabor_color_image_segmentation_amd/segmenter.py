@@ -79,7 +79,9 @@ class _CaptureGuard:
     What a thread that is NOT capturing may do beside an open capture was measured on the box (tools/dbg/capture_probe.py,
     profiles/r5_notes.md): kernel launches, stream / event synchronisation, hipMalloc, pinned allocation and copies are all
     fine; ``hipDeviceSynchronize`` is refused with hipErrorStreamCaptureUnsupported AND invalidates the other thread's
-    capture - so no path of this package calls ``torch.cuda.synchronize``: every wait is on a stream or an event."""
+    capture - so no path of this package calls ``torch.cuda.synchronize``: every wait is on a stream or an event. A CALLER's
+    thread still can: ``capture`` therefore runs on a helper thread (see there), which confines the damage of an invalidated
+    capture to a thread and a stream nobody uses again."""
 
     def __init__(self):
         import threading
@@ -88,20 +90,48 @@ class _CaptureGuard:
         self._failed = []            # graphs whose capture was refused or invalidated: kept alive on purpose (see above)
         self._warned = set()
 
-    def capture(self, torch, graph, body):
-        """Capture ``body()`` into ``graph`` (thread_local error mode: only this thread is restricted while it captures).
-        Returns True, or False when the capture was refused (the caller then launches eagerly)."""
+    def capture(self, torch, graph, body, device=None):
+        """Capture ``body()`` into ``graph`` (thread_local error mode). Returns True, or False when the capture was refused or
+        invalidated (the caller then launches eagerly).
+
+        The capture runs on a HELPER THREAD, and on a stream of its own. Measured on the box (tools/dbg/invalidated_capture_probe.py,
+        capture_helper_thread_probe.py, profiles/r6_notes.md): a device-wide synchronize from ANY other thread - a caller's loader, a
+        logger - is refused by HIP while a capture is open in whatever mode AND invalidates that capture, and an invalidated capture
+        leaves the thread that opened it unable to launch another kernel (hipErrorStreamCaptureInvalidated from every later launch;
+        hipStreamEndCapture does not clear it) and its capture stream in the invalidated state for good. Bound to the helper, that
+        damage dies with it: the caller's thread and streams stay usable, the shape runs as eager launches, and the next capture
+        gets a fresh helper and a fresh stream."""
         import gc
+        import threading
         with self._lock:
             gc.collect()             # dead cycles that hold graphs: finalise them NOW, not between capture_begin and capture_end
             was_enabled = gc.isenabled()
             gc.disable()
+            result = {}
+            stream = torch.cuda.Stream(device=device)
+
+            def run():
+                try:
+                    if device is not None:
+                        torch.cuda.set_device(device)
+                    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                        body()
+                    result["ok"] = True
+                except RuntimeError as e:          # (GcsError and torch.AcceleratorError are RuntimeErrors)
+                    result["err"] = e
+                except BaseException as e:         # anything else is the caller's to see
+                    result["raise"] = e
+
             try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    body()
-                return True
-            except RuntimeError:
-                self._failed.append(graph)
+                helper = threading.Thread(target=run, name="gcs-graph-capture")
+                helper.start()
+                helper.join()
+                if "raise" in result:
+                    self._failed.append((graph, stream))
+                    raise result["raise"]
+                if result.get("ok"):
+                    return True
+                self._failed.append((graph, stream))      # never destroyed, never reused (see the class docstring)
                 return False
             finally:
                 if was_enabled:
@@ -817,7 +847,7 @@ class Segmenter:
                 # capture under the module's guard (_CaptureGuard: serialised, collector off for exactly that long, retired
                 # graphs parked meanwhile); a refused capture (e.g. the caller's own capture is open on this thread) is reported
                 # once and the shape then runs as eager launches
-                if not _CAPTURES.capture(torch, graph, step):
+                if not _CAPTURES.capture(torch, graph, step, dev):
                     _CAPTURES.fell_back(key, "torch.cuda.graph raised RuntimeError")
                     graph = None
                     torch.cuda.current_stream(dev).synchronize()

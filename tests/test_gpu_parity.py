@@ -310,7 +310,7 @@ def test_a_refused_capture_warns_once_and_runs_eagerly(torch_cuda):
     seg = Segmenter(n_iter=2)
     img = _synth(1, 48, 80, seed=83)
     real = sg._CAPTURES.capture
-    sg._CAPTURES.capture = lambda torch_, graph, body: False    # what a RuntimeError out of torch.cuda.graph turns into
+    sg._CAPTURES.capture = lambda torch_, graph, body, device=None: False    # what a RuntimeError out of torch.cuda.graph turns into
     try:
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")

@@ -32,7 +32,11 @@ for spec in args.libs:
     _lib.LIB_PATH = os.path.abspath(path)
     # an older build may be compared as long as the entry points used here kept their signatures (ABI 15 -> 16 only dropped
     # gcs_labels_raster_u8 and turned the label slab into a raster map)
-    _lib.ABI_VERSION = ctypes.CDLL(_lib.LIB_PATH).gcs_abi_version()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.ABI_VERSION = raw.gcs_abi_version()
+    if not hasattr(_lib, "_ALL_SIGNATURES"):
+        _lib._ALL_SIGNATURES = dict(_lib.SIGNATURES)
+    _lib.SIGNATURES = {k: v for k, v in _lib._ALL_SIGNATURES.items() if hasattr(raw, k)}   # an older build lacks the newest entry points
     segs[name] = Segmenter(n_scales=ns, n_orient=no)
 n_sets = B if args.mode == "per_image" else 1
 

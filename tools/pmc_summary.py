@@ -4,7 +4,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0][-40:]
+        name = r["Kernel_Name"].split("(")[0][-64:]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in sorted(acc.items()):
     if not any(x in k for x in ("gabor", "kmeans_pass", "kmeans_assign")):
