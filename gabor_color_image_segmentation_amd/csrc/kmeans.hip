@@ -275,6 +275,35 @@ constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 2
 // WAVES = 4 (narrow pass: wave w owns block w of the tile) or 8 (wide pass: 131 KB of LDS allow one workgroup per CU, so
 // it brings 8 waves: wave w works on block w & 3; in the assign phase it takes the block's 32-pixel half w >> 2, in the
 // update phase all 64 pixels for half of the plane tiles -> half the accumulators, twice the waves to hide latency).
+// -DGCS_KP_PHASES (debugging aid, tools/dbg/pass_phases.py): every wave of kmeans_pass_mfma_kernel adds up, over its tile loop,
+// the shader-clock cycles it spends in each phase of a tile (s_memtime around: staging writes | first barrier | next tile's loads
+// | assign | update | second barrier) and stores the six sums behind the loop. Costs ~10 % of the wave's cycles; never in the product.
+#ifdef GCS_KP_PHASES
+__device__ unsigned long long g_kp_phases[1024 * 4 * 8];
+extern "C" int gcs_debug_kp_phases(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kp_phases), sizeof(unsigned long long) * 1024 * 4 * 8);
+}
+#define KP_PHASE_DECL unsigned long long kp_ph[6] = {0, 0, 0, 0, 0, 0}, kp_t0 = __builtin_amdgcn_s_memtime(), kp_tiles = 0
+#define KP_PHASE(k)                                                   \
+    do {                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        kp_ph[k] += t_ - kp_t0;                                       \
+        kp_t0 = t_;                                                   \
+    } while (0)
+#define KP_PHASE_STORE                                                                                           \
+    do {                                                                                                         \
+        const int wg_ = (int)(blockIdx.y * gridDim.x + blockIdx.x);                                              \
+        if (lane == 0 && wg_ < 1024) {                                                                           \
+            for (int k_ = 0; k_ < 6; ++k_) g_kp_phases[(wg_ * 4 + (wid & 3)) * 8 + k_] = kp_ph[k_];             \
+            g_kp_phases[(wg_ * 4 + (wid & 3)) * 8 + 6] = kp_tiles;                                               \
+        }                                                                                                        \
+    } while (0)
+#else
+#define KP_PHASE_DECL
+#define KP_PHASE(k)
+#define KP_PHASE_STORE
+#endif
+
 // SPLIT (round 6): the split slab of csrc/common.h (narrow pass only). NST then counts staging ROUNDS: an ITEM = 16 consecutive slots of a
 // tile = 16 low bytes + 8 bytes of MID nibbles (+ 8 bytes of TOP nibbles when the tile's flag word says that one of them is set),
 // unpacked into the same LDS image as the wide slab's: 16 pixels of a level-0 plane row, or the 4 x 4 parents of one block of a
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     // its columns 16 PLANES - sums[(j, b)][plane] = sel[(j, b)][(px, t)] * X[(px, t)][plane] with sel = the one-hot digit where t == b -,
     // so that the B operand is a plane row AS IT LIES in LDS (8 pixels x (lo, hi) = one 16-byte read, no byte de-interleave: 40 v_perm
     // per tile and wave less) and 80 plane rows are 5 accumulator tiles instead of 10 (the deep-bank pass's form, kmeans_pass_native_kernel).
-    constexpr bool UPD2 = SPLIT && KT == 1 && WAVES == 4;
+    constexpr bool UPD2 = SPLIT && KT == 1;
     constexpr int NACC = UPD2 ? DSTEPS : NT_OWN;
     v4i accu[NACC];
 #pragma unroll
@@ -669,13 +698,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     if constexpr (SPLIT) {
         if (ltile < nlist) load_next_split(tile_has_top(0));
     }
+    KP_PHASE_DECL;
     for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
         // (split slab) the flag of the tile loaded in this iteration: read from LDS here, used behind the barrier
         int flag_next = 1;
         if constexpr (SPLIT) flag_next = it_l < KP_FLAGS ? (int)s_flag[it_l < KP_FLAGS ? it_l : 0] : 1;
         stage_write();
+        KP_PHASE(0);
         __syncthreads();
+        KP_PHASE(1);
         // the next tile's loads go out first: a wave issuing them outranks the waves of the other workgroups that
         // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
         __builtin_amdgcn_s_setprio(3);
@@ -684,6 +716,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             else stage_load(phys(ltile + G));
         }
         __builtin_amdgcn_s_setprio(0);
+        KP_PHASE(2);
         if (!SPLIT && lo.n_levels > 2) {
             expand_deep();
             __syncthreads();
@@ -775,6 +808,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 }
             }
         }
+        KP_PHASE(3);
         if (WAVES == 8 && do_acc) __syncthreads();             // the block's labels come from two waves
         // -------- update: one-hot MFMA over the block's 64 pixels
         if constexpr (UPD2) {
@@ -794,11 +828,37 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                     oh[2 * i] = (int)__builtin_amdgcn_perm(0u, d, sel01);       // (px, t): the digit where t == b, 0 elsewhere
                     oh[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, d, sel23);
                 }
-#pragma unroll
-                for (int pt = 0; pt < DSTEPS; ++pt) {
-                    const v4i bx_ = *reinterpret_cast<const v4i *>(&s_tile[(16 * pt + un) * KP_PITCH + (wave * 64 + hf * 32 + 8 * ug) * 2]);
-                    accu[pt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bx_, accu[pt], 0, 0, 0);
-                }
+                // The five plane tiles' operand reads go out TOGETHER, each MFMA waits for its own (counted lgkmcnt: LDS returns in
+                // order; whatever else is in flight only makes a wait longer). Left to itself hipcc reads, waits and multiplies
+                // tile by tile - five exposed LDS latencies per half - whatever the source order and however many registers are
+                // free (profiles/r6_notes.md); asm loads are invisible to its wait counting, hence the explicit waits.
+                static_assert(DSTEPS == 5, "the update's read batch is written out for five plane tiles");
+                const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)
+                                    &s_tile[un * KP_PITCH + (wave * 64 + hf * 32 + 8 * ug) * 2];
+                v4i bq[DSTEPS];
+                asm volatile("ds_read_b128 %0, %5\n\t"
+                             "ds_read_b128 %1, %5 offset:%c6\n\t"
+                             "ds_read_b128 %2, %5 offset:%c7\n\t"
+                             "ds_read_b128 %3, %5 offset:%c8\n\t"
+                             "ds_read_b128 %4, %5 offset:%c9"
+                             : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bq[4])
+                             : "v"(ba), "i"(16 * KP_PITCH), "i"(32 * KP_PITCH), "i"(48 * KP_PITCH), "i"(64 * KP_PITCH)
+                             : "memory");
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                asm volatile("" : "+v"(bq[0]));
+                accu[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[0], accu[0], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                asm volatile("" : "+v"(bq[1]));
+                accu[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[1], accu[1], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                asm volatile("" : "+v"(bq[2]));
+                accu[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[2], accu[2], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                asm volatile("" : "+v"(bq[3]));
+                accu[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[3], accu[3], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(bq[4]));
+                accu[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[4], accu[4], 0, 0, 0);
             }
           }
         } else
@@ -841,8 +901,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 if (bx < 0) { bx += lo.bx_n; --by; }
             }
         }
+        KP_PHASE(4);
         __syncthreads();
+        KP_PHASE(5);
+#ifdef GCS_KP_PHASES
+        ++kp_tiles;
+#endif
     }
+    KP_PHASE_STORE;
 
     if (!do_acc) return;
     if constexpr (UPD2) {
@@ -1541,6 +1607,8 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NR_, KP_DSTEPS_NARROW, 4, true>), dim3(parts, B), dim3(256), 0, stream, \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,             \
                        reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
+            // (measured and dropped, profiles/r6_notes.md: eight waves per workgroup at two workgroups per CU - 0.28 against 0.15 ms
+            //  per pass -, the assign A fragments in LDS, the second sub-tile's transposed reads under the first one's epilogue)
             if (k <= 8 && rounds <= 3) { GCS_KP_LAUNCHS(1, 3); }
             else if (k <= 8) { GCS_KP_LAUNCHS(1, 5); }
             else { GCS_KP_LAUNCHS(2, 5); }
