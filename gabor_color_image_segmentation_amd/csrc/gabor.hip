@@ -1054,7 +1054,10 @@ extern "C" int gcs_gabor_features(const uint8_t *img, int B, int H, int W, const
     // the two launches take 19 us each, one after the other; the slot is called once per image, script.py:22-30).
     long long tiles_all = 0;
     for (int L = 0; L < lo.n_levels; ++L) tiles_all += (long long)B * ((half_tiles(L) + 1) / 2);
-    const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count();
+    // (not for a split-slab bank whose level is three row tiles that cannot run as groups - 9 to 11 filters per level -: the fused
+    //  three-tile kernel with both split store paths live spills 50 VGPRs; such a call takes the two single-level launches)
+    const bool fuse_small = lo.n_levels == 2 && tiles_all <= 2LL * gcs_cu_count() &&
+                            !(lo.split && mtiles(lo.FL[0]) == 3 && lo.FL[0] % 4 != 0);
     // split slab: which flag bytes the pre-pass of level L clears (csrc/common.h; level 0 also those of absent levels)
     auto flag_zero = [&](int zmask) {
         GaborFlagZero z{};

@@ -16,6 +16,11 @@ cp $R/gpurun_out/profiles/${TAG}_kernel_stats.csv $R/gpurun_out/profiles/kernel_
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-other-mode > $OUT/bench_$c.log 2>&1
 done
-python $R/tools/hbm_traffic.py $OUT $R/gpurun_out/profiles/${TAG}_hbm_traffic.json
+# FETCH_SIZE factor of the split pass's access pattern (16 + 8 bytes per lane), from the streaming microbenchmark's known byte count
+if [ -x $R/tools/ubench/read_stream ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- $R/tools/ubench/read_stream > $OUT/calib.log 2>&1 || true
+  python $R/tools/hbm_calibrate.py $OUT/calib $R/gpurun_out/profiles/${TAG}_fetch_calibration.json || true
+fi
+python $R/tools/hbm_traffic.py $OUT $R/gpurun_out/profiles/${TAG}_hbm_traffic.json $R/gpurun_out/profiles/${TAG}_fetch_calibration.json
 cp $R/gpurun_out/profiles/${TAG}_hbm_traffic.json $R/gpurun_out/profiles/hbm_traffic_latest.json
 cat $R/gpurun_out/profiles/${TAG}_hbm_traffic.json
