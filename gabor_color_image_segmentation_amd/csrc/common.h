@@ -32,7 +32,8 @@ static inline int mtiles(int F) { return (F + 3) / 4; }   // 32-row MFMA tiles o
 // The feature slab keeps every pyramid level at its own resolution (SPEC.md §3). The image is cut into
 // 8x8-pixel BLOCKS; a block owns 8x8 level-0 pixel SLOTS (iy, ix) and the slots of their parents: 4x4 level-1, 2x2 level-2
 // and 1 level-3 (the parent of slot (iy, ix) at level L is slot (iy >> L, ix >> L)). Four consecutive blocks form a TILE =
-// the 256 pixels one k-means workgroup step handles (one block per wave). A tile is ONE contiguous run of bytes:
+// the 256 pixels one k-means workgroup step handles (one block per wave). In the WIDE slab (deep banks; every bank before
+// round 6) a tile is ONE contiguous run of bytes:
 //     [level 0: D_0 planes x 256 u16][level 1: D_1 x 64][level 2: D_2 x 16][level 3: D_3 x 4]
 // (each level block padded to 16 bytes), slot order inside a plane = (block in tile, slot row, slot column) of that
 // level's sub-block. Planes are in PHYSICAL order: level-major, then channel, then filter-in-level; logical

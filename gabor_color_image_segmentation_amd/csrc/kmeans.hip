@@ -2,9 +2,11 @@
 // The reference ships no code for this path; slot: /root/reference/BSD_metrics/script.py:30.
 //
 // Kernels
-//   kmeans_pass_mfma_kernel  one Lloyd pass (assign + update) on the matrix cores for D <= 207; HBM-bound stream of the
+//   kmeans_pass_mfma_kernel  one Lloyd pass (assign + update) on the matrix cores for D <= 207; a stream of the
 //                            slab, which keeps pyramid level L at 1/4^L of the pixels: a tile's coarse planes are
-//                            replicated over their 2^L x 2^L blocks while they are staged into LDS.
+//                            replicated over their 2^L x 2^L blocks while they are staged into LDS. 4x6-style banks
+//                            (at most two levels, D <= 79) read the SPLIT slab: 12 of the 16 bits of every value, the
+//                            last 4 for flagged tiles only (template flag SPLIT).
 //   kmeans_assign_kernel     generic pass for D >= 208: exact integer argmin via fp32 byte-digit FMAs (all partial
 //                            sums < 2^24, hence exact), LDS-replicated u32 accumulators.
 //   kmeans_reduce_kernel     element-major partial sums -> int64 sums (+ the centroid update when single-rank).
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 #pragma unroll
     for (int nt = 0; nt < NACC; ++nt) accu[nt] = v4i{0, 0, 0, 0};
 
-    // ---- staging: the tile is ONE contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
+    // ---- staging (wide slab; the split slab's items: stage_load_split and the SPLIT branch of stage_write below): the tile is ONE
+    //      contiguous run of tile_bytes (csrc/common.h), already offset-binary. Chunk
     //      ci = tid + 256*i is 16 bytes at byte 16*ci:
     //        level-0 chunks (the first 32*D_0) are 8 pixels of plane row ci>>5: copied as they are;
     //        level-1 chunks (the next 8*D_1) are 2 rows x 4 pixels of one block's 4x4 parents: each row is replicated
