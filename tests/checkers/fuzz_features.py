@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the Gabor stage + label map against the C oracle: random shapes (odd sizes, tiny, one tile row of
-a single valid row, ...), batch sizes, banks (1-8 scales, odd orientation counts, ksize 1-15), k. Prints one line per case and
-a summary; exit code 1 on any mismatch. usage: fuzz_features.py [n_cases] [seed]"""
+a single valid row, ...), batch sizes, banks (1-8 scales, odd orientation counts, ksize 1-15), k. Half of the cases carry one to
+three full-contrast square-wave patches (random period, direction, size, place): values of 4096 and more, i.e. flagged tiles of the
+split slab (round 6) among clean ones, also on packed edge strips. Prints one line per case and a summary; exit code 1 on any
+mismatch. usage: fuzz_features.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,6 +31,17 @@ for case in range(n_cases):
     imgs = synthetic_batch(b, h, w, seed=int(rng.integers(1 << 30)))
     if rng.random() < 0.15:
         imgs[:] = rng.choice([0, 255])                 # extreme constant pixels
+    n_patch = int(rng.integers(1, 4)) if rng.random() < 0.5 else 0
+    for _ in range(n_patch):                           # full-contrast square waves: values >= 4096 under them
+        size = int(rng.integers(4, 25))
+        ph, pw = min(size, h), min(size, w)
+        y0, x0 = int(rng.integers(0, h - ph + 1)), int(rng.integers(0, w - pw + 1))
+        if rng.random() < 0.4:                         # push the patch onto the right / bottom edge (packed strips)
+            y0, x0 = (h - ph, x0) if rng.random() < 0.5 else (y0, w - pw)
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        ang = rng.random() * np.pi
+        wave = np.sin(2 * np.pi * float(rng.choice([0.2, 0.3, 0.4, 0.5])) * (xx * np.cos(ang) + yy * np.sin(ang)) + 0.3) >= 0
+        imgs[int(rng.integers(b)), y0:y0 + ph, x0:x0 + pw] = np.where(wave, 255, 0).astype(np.uint8)[..., None]
     try:
         seg = Segmenter(n_scales=ns, n_orient=no, ksize=ks, k=k, n_iter=n_iter)
     except Exception as e:                             # e.g. a degenerate bank the packer refuses
@@ -41,7 +54,8 @@ for case in range(n_cases):
     lab = seg.segment_batch(imgs, mode=mode)
     want = co.segment_batch(imgs, bank.tapq, bank.shift, no, k=k, n_iter=n_iter, mode=mode)
     ok_l = np.array_equal(lab, want)
-    print(f"case {case}: B {b} {h}x{w} bank {ns}x{no} ks {ks} k {k} it {n_iter} {mode}: features {'ok' if ok_f else 'MISMATCH'} labels {'ok' if ok_l else 'MISMATCH'}", flush=True)
+    big = int((ref >= 4096).sum())
+    print(f"case {case}: B {b} {h}x{w} bank {ns}x{no} ks {ks} k {k} it {n_iter} {mode} patches {n_patch} values>=4096 {big}: features {'ok' if ok_f else 'MISMATCH'} labels {'ok' if ok_l else 'MISMATCH'}", flush=True)
     if not (ok_f and ok_l):
         bad += 1
         if not ok_f:
