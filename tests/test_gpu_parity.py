@@ -665,7 +665,10 @@ def test_host_path_variants_agree_with_the_device_path(torch_cuda):
 def test_randomised_shapes_banks_and_codebooks_against_the_c_oracle(torch_cuda):
     """tests/checkers/fuzz_features.py: 60 random cases (tiny / odd / one-row-remainder shapes, batches 1-9, banks of 1-8 scales with
     odd orientation counts, ksize 1-15, k 1-16, both codebook modes, constant extreme images): features and labels equal the C
-    oracle's bit for bit. (400 further cases were run once in round 3, 300 - seed 4, with the packed edge strips - in round 4: 0 mismatches.)"""
+    oracle's bit for bit; since round 6 half of the cases carry full-contrast patches (flagged tiles of the split slab). (400 further
+    cases were run once in round 3, 300 - seed 4, with the packed edge strips - in round 4, 400 - seed 11 - in round 6: 210 of them on
+    the split slab, 128 of those with values >= 4096, 96 of those on shapes with packed edge strips; 0 mismatches,
+    profiles/r6_fuzz400.log.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
