@@ -230,13 +230,38 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
     return d;
 }
 
-// Tile loads of the passes. A slab far larger than the 256 MiB Infinity Cache is read once per pass and nothing of it survives
-// to the next one: its loads carry the nontemporal hint (global_load_dwordx4 ... nt) and stop evicting what other kernels
-// keep there. Same-box A/B, round 4, batch 64 (895 MB): in a sequence that interleaves other work (tools/ab.py) the pass after
-// the Gabor stage 0.181 -> 0.155 ms, the others 0.159 -> 0.154 ms, step 2.06 -> 2.00 ms; in bench.py's back-to-back steps no
-// difference (4 820 / 4 777 vs 4 822 / 4 769 Mpix/s). Slabs the cache can hold a good part of lose with the hint (16 images,
-// 224 MB: 4 007 -> 3 910 Mpix/s; 8 images: 2 996 -> 2 886): the host sets `nt` from the slab size (profiles/r4_notes.md).
-constexpr size_t KP_NT_MIN_SLAB_BYTES = (size_t)512 << 20;
+// Tile loads of the passes and the Infinity Cache (256 MiB). Passes sweep the slab in alternating directions, so a pass STARTS on the
+// bytes its predecessor read last: those are worth keeping in the cache; everything before them is evicted before anyone returns
+// and allocating it only costs. The split-slab pass and the deep-bank pass therefore load the list positions below `nt_limit` with
+// the nontemporal hint (buffer_load ... nt) and the last KP_MALL_KEEP_DEFAULT bytes of every sweep plain. Measured, round 6 (same box,
+// two interleaved rounds each; tools/dbg/mall_keep_sweep.sh, profiles/r6_mall_keep_sweep.txt), whole steps of 64 images:
+//   deep-bank pass (8x8 bank, 1 265 MB per pass, HBM-bound): every load plain 0.237 - 0.243 ms per pass, step 3 075 - 3 117 Mpix/s;
+//     every load nt 0.220 - 0.223 ms, 3 172; the last 128 / 192 / 256 / 320 / 384 / 512 MB plain: 0.215 - 0.218 / 0.216 - 0.217 /
+//     0.214 - 0.219 / 0.214 - 0.217 / 0.215 - 0.216 / 0.219 - 0.220 ms, step 3 193 - 3 202 / 3 216 - 3 228 / 3 213 - 3 252 /
+//     3 216 - 3 236 / 3 209 - 3 213 / 3 199 - 3 215 Mpix/s: + 4 % with 192 - 320 MB (5.9 TB/s of algorithmic bytes);
+//   split-slab pass (4x6 bank, 671 MB per pass, bound by its dependency chains): every load plain 5 277 - 5 296 Mpix/s, every load
+//     nt 5 144 - 5 201 (the next pass no longer finds the end of the sweep in the cache), the last 128 / 192 / 256 / 320 / 384 /
+//     512 MB plain: 5 279 - 5 289 / 5 272 - 5 316 / 5 308 - 5 325 / 5 316 - 5 320 / 5 304 - 5 335 / 5 202 - 5 316: + 0.7 % at 256 MB.
+//     (Isolated passes of a sequence that interleaves other work, tools/ab.py: every load nt 0.141 - 0.144 against 0.151 - 0.161 ms.)
+// History: round 4 introduced the hint as `nt ? __builtin_nontemporal_load(p) : *p` - hipcc merges the two arms into ONE plain
+// load (and two branches around global loads likewise): from that commit until round 6 no pass kernel contained an `nt` load
+// (ISA), whatever the flag said. The cache policy of a raw buffer load is an immediate operand: two instructions that stay two.
+// The wide-slab kernels of kmeans_pass_mfma_kernel (banks outside the BASELINE configurations, -DGCS_NO_SPLIT) load plain.
+constexpr long long KP_MALL_KEEP_DEFAULT = (long long)256 << 20;
+// (tuning hook for same-box runs: GCS_KP_MALL_MB, read once; 0 = every load nt, a huge value = every load plain)
+static long long kp_mall_keep_bytes() {
+    static const long long v = [] {
+        const char *e = getenv("GCS_KP_MALL_MB");
+        return e ? (long long)atoll(e) << 20 : KP_MALL_KEEP_DEFAULT;
+    }();
+    return v;
+}
+// list positions (per sweep list: the whole batch, or one image with per-image codebooks) below the result are loaded `nt`
+static int kp_nt_limit(const GcsLayout &lo, int B, int n_sets, long long tile_stream_bytes) {
+    const long long lists = n_sets == B ? B : 1, nlist = (long long)lo.ntiles * (n_sets == B ? 1 : B);
+    const long long keep_tiles = kp_mall_keep_bytes() / tile_stream_bytes / lists;
+    return (int)(nlist > keep_tiles ? nlist - keep_tiles : 0);
+}
 // Logical feature of plane `pl` of level LL, and its inverse, with the level a COMPILE-TIME constant: `lo` is a by-value kernel
 // argument, and indexing one of its arrays with a per-lane level (gcs_logical_of_plane / gcs_plane_of_logical on a run-time plane)
 // makes hipcc fetch the element from the kernarg segment with a VECTOR load and wait for it - four dependent loads and
@@ -253,11 +278,6 @@ __device__ __forceinline__ int kp_plane_on_level(const GcsLayout &lo, int c, int
     const int fl = f - 2 * LL * lo.n_orient;                  // filter index inside level LL
     return (LL < lo.n_levels && fl >= 0 && fl < lo.FL[LL]) ? lo.row0[LL] + c * lo.FL[LL] + fl : -1;
 }
-template <typename T>
-__device__ __forceinline__ T kp_load(const T *p, bool nt) {
-    return nt ? __builtin_nontemporal_load(p) : *p;
-}
-
 constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
                                           // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
 constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 46 KB LDS, 3 workgroups / CU
@@ -316,9 +336,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials, void *__restrict__ raster,
-    int raster_u8, int nt_flag) {
+    int raster_u8, int nt_flag) {                      // (nt_flag: the split slab's nt_limit, see lloyd_pass; unused by the wide kernels)
     constexpr int KP_ROWS = 16 * DSTEPS, KP_DSTEPS = DSTEPS, KP_NT = 2 * DSTEPS;
-    const bool nt_loads = __builtin_amdgcn_readfirstlane(nt_flag) != 0;     // (uniform: a scalar branch around the two load forms)
     constexpr int NTHR = 64 * WAVES;                         // threads per workgroup
     constexpr int NT_OWN = WAVES == 8 ? (KP_NT + 1) / 2 : KP_NT;   // update plane tiles a wave accumulates
     // compact copy of pyramid levels >= 2 of one tile (level 1 is replicated straight from the staging registers):
@@ -483,22 +502,45 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     auto stage_load = [&](int tile) {
         const v4i *src = reinterpret_cast<const v4i *>(fb + (size_t)tile * lo.tile_bytes);
 #pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = kp_load(&src[ssrc[i]], nt_loads);
+        for (int i = 0; i < NST; ++i) st[i] = src[ssrc[i]];
     };
     // split slab: the tile whose LO run starts at p_lo and whose MID run at p_mid (uniform pointers; 32-bit lane offsets: the loads
     // take an SGPR base and need no vector address arithmetic); the TOP run only when the tile's flag word is set
-    auto stage_load_split = [&](const unsigned char *p_lo, const unsigned char *p_mid, bool top) {
+    // Raw buffer loads (one descriptor over the tile's LO run; the MID and TOP runs at scalar offsets from it): the cache policy is an
+    // IMMEDIATE of the intrinsic, so the two forms - plain, and `nt` for the part of the sweep that no later pass finds in the Infinity
+    // Cache (see lloyd_pass) - are different instructions. Written as `nt ? __builtin_nontemporal_load(p) : *p`, or as two branches
+    // around global loads, hipcc merges them into ONE plain load: until round 6 not a single `nt` load was left in the pass kernels
+    // (ISA). The address is SGPR descriptor + 32-bit lane offset + SGPR offset: no vector address arithmetic (hipcc built 64-bit lane
+    // addresses for the global loads: a v_lshl_add_u64 per load and 18 VGPRs of offsets).
+    auto stage_load_split = [&](const unsigned char *p_lo, unsigned mid_rel, bool top, bool nt) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p_lo), 0, -1, 0x00020000);
+        const unsigned top_rel = mid_rel + (unsigned)(lo.top_off - lo.mid_off);
+        auto go = [&](auto aux_c) {
+            constexpr int AUX = decltype(aux_c)::value;          // gfx940+: bit 1 = nt
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const unsigned o = (unsigned)ssrc[i] * 16u;
-            st[i] = kp_load(reinterpret_cast<const v4i *>(p_lo + o), nt_loads);
-            sm[i] = kp_load(reinterpret_cast<const v2i *>(p_mid + (o >> 1)), nt_loads);
-        }
-        if (top) {
-            const unsigned char *p_top = p_mid + (lo.top_off - lo.mid_off);
+            for (int i = 0; i < NST; ++i) {
+                const unsigned o = (unsigned)ssrc[i] * 16u;
+                st[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, AUX));
+                sm[i] = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(o >> 1), (int)mid_rel, AUX));
+            }
+            if (top) {
 #pragma unroll
-            for (int i = 0; i < NST; ++i) stt[i] = kp_load(reinterpret_cast<const v2i *>(p_top + (unsigned)ssrc[i] * 8u), nt_loads);
-        }                                  // (no TOP run: stage_write's unpack does not read stt then)
+                for (int i = 0; i < NST; ++i)
+                    stt[i] = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((unsigned)ssrc[i] * 8u), (int)top_rel, AUX));
+            } else {
+                // no TOP run: stage_write's unpack does not read stt then. The registers are given a fresh (undefined) value so that
+                // no old value lives through this path: with one, hipcc merged the paths through copies of the registers just
+                // loaded - behind s_waitcnt vmcnt(0), i.e. every tile waited for its successor's loads at once (ISA, round 6)
+#pragma unroll
+                for (int i = 0; i < NST; ++i) {
+                    v2i u;
+                    asm("" : "=v"(u));
+                    stt[i] = u;
+                }
+            }
+        };
+        if (nt) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 0>{});
     };
     typedef __attribute__((address_space(3))) v4i *lds_v4i_ptr;
     // (wide slab) a level-1 chunk of the LDS image: coarse row 0 = pixels (v0.lo, v0.hi, v1.lo, v1.hi), row 1 = (v2.., v3..): each
@@ -672,34 +714,37 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     // one of two precomputed 64-bit strides per pointer -, and the iteration whose flag that load needs
     const int qG = __builtin_amdgcn_readfirstlane(G / ntiles);
     int tin_l = tin, it_l = 0;
-    const unsigned char *p_lo_l = nullptr, *p_mid_l = nullptr;
-    long long d_lo[2] = {0, 0}, d_mid[2] = {0, 0};           // [wrap]
+    const unsigned char *p_lo_l = nullptr;
+    unsigned mid_rel_l = 0;                                  // the tile's MID run, in bytes from its LO run (< 2^32: host check)
+    long long d_lo[2] = {0, 0};                              // [wrap]
+    int d_rel[2] = {0, 0};
     if constexpr (SPLIT) {
         const int bi0 = __builtin_amdgcn_readfirstlane(phys(g < nlist ? g : 0) / ntiles);
         const unsigned char *img = fb + (size_t)bi0 * lo.img_bytes;
         p_lo_l = img + (size_t)tin * lo.S;
-        p_mid_l = img + lo.mid_off + (size_t)tin * (lo.S >> 1);
+        mid_rel_l = (unsigned)(lo.mid_off - (size_t)tin * (lo.S >> 1));      // mid_off + tin S / 2 - tin S
         const long long sg = reverse ? -1 : 1;
         d_lo[0] = sg * ((long long)qG * lo.img_bytes + (long long)s1 * lo.S);
         d_lo[1] = sg * ((long long)(qG + 1) * lo.img_bytes + (long long)(s1 - ntiles) * lo.S);
-        d_mid[0] = sg * ((long long)qG * lo.img_bytes + (long long)s1 * (lo.S >> 1));
-        d_mid[1] = sg * ((long long)(qG + 1) * lo.img_bytes + (long long)(s1 - ntiles) * (lo.S >> 1));
+        d_rel[0] = (int)(sg * -(long long)s1 * (lo.S >> 1));
+        d_rel[1] = (int)(sg * -(long long)(s1 - ntiles) * (lo.S >> 1));
     }
     auto tile_has_top = [&](int it) -> bool {
         return __builtin_amdgcn_readfirstlane(it < KP_FLAGS ? (int)s_flag[it < KP_FLAGS ? it : 0] : 1) != 0;
     };
-    auto load_next_split = [&](bool top) {
+    const int nt_limit = __builtin_amdgcn_readfirstlane(nt_flag);   // split slab: list positions below it are loaded `nt`
+    auto load_next_split = [&](bool top, int pos) {
         top_regs = top;
-        stage_load_split(p_lo_l, p_mid_l, top_regs);
+        stage_load_split(p_lo_l, mid_rel_l, top_regs, pos < nt_limit);
         const int tn = reverse ? tin_l - s1 : tin_l + s1;
         const bool wrap = reverse ? tn < 0 : tn >= ntiles;
         tin_l = wrap ? (reverse ? tn + ntiles : tn - ntiles) : tn;
         p_lo_l += wrap ? d_lo[1] : d_lo[0];
-        p_mid_l += wrap ? d_mid[1] : d_mid[0];
+        mid_rel_l += (unsigned)(wrap ? d_rel[1] : d_rel[0]);
         ++it_l;
     };
     if constexpr (SPLIT) {
-        if (ltile < nlist) load_next_split(tile_has_top(0));
+        if (ltile < nlist) load_next_split(tile_has_top(0), ltile);
     }
     KP_PHASE_DECL;
     for (; ltile < nlist; ltile += G) {
@@ -715,7 +760,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         // are in their compute phase (18 interleaved A/B runs: 0.252 -> 0.244 ms per pass)
         __builtin_amdgcn_s_setprio(3);
         if (ltile + G < nlist) {                              // in flight during the MFMAs
-            if constexpr (SPLIT) load_next_split(__builtin_amdgcn_readfirstlane(flag_next) != 0);
+            if constexpr (SPLIT) load_next_split(__builtin_amdgcn_readfirstlane(flag_next) != 0, ltile + G);
             else stage_load(phys(ltile + G));
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1063,7 +1108,6 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
     const unsigned char *__restrict__ feats, const uint16_t *__restrict__ cent, GcsLayout lo, int K, int per_image,
     int parts, int parts_eff, int reverse, int row_lo, int row_hi, uint64_t *__restrict__ partials,
     void *__restrict__ raster, int raster_u8, int nt_flag) {
-    const bool nt_loads = __builtin_amdgcn_readfirstlane(nt_flag) != 0;
     // LDS, one carve-up: [tile as in HBM, rows padded | (U, R2) tables | assign A fragments | labels | key bases | n_j].
     // The transposed reads of level 3 run up to 64 bytes past the tile (unused columns): they land in the tables.
     constexpr int TILE_B = NL == 2 ? NV_OFF2 : NL == 3 ? NV_OFF3 : NV_END;
@@ -1126,18 +1170,26 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         sadr[i - N0] = ((unsigned)(size_t)(lds_uchar_ptr)s_mem + (unsigned)d) << 16 | (unsigned)(ci * 16);
         if (NL > 2 && 256 * i < c3s && 256 * i + 255 >= c2s) split |= 1 << i;
     }
-    auto stage_load = [&](int tile) {                       // uniform 64-bit tile base + 32-bit lane offset
+    // Raw buffer loads: a descriptor over the tile (uniform base) + 32-bit lane offset; the cache policy is an immediate of the
+    // intrinsic, so the plain and the `nt` form both survive (see stage_load_split of kmeans_pass_mfma_kernel and lloyd_pass)
+    auto stage_load = [&](int tile, bool nt) {
         const unsigned char *tb = fb + (size_t)tile * lo.tile_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tb), 0, -1, 0x00020000);
         unsigned o0 = (unsigned)tid * 16u;
         asm volatile("" : "+v"(o0));                        // (opaque: see below)
+        auto go = [&](auto aux_c) {
+            constexpr int AUX = decltype(aux_c)::value;     // gfx940+: bit 1 = nt
 #pragma unroll
-        for (int i = 0; i < N0; ++i) st[i] = kp_load(reinterpret_cast<const v4i *>(tb + i * 4096 + o0), nt_loads);
+            for (int i = 0; i < N0; ++i) st[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, i * 4096, AUX));
 #pragma unroll
-        for (int i = N0; i < NV_NST; ++i) {
-            unsigned o = sadr[i - N0] & 0xffffu;            // (opaque: hoisted out of the tile loop as eight zero-extended 64-bit
-            asm volatile("" : "+v"(o));                     //  offsets, these spilled - and a reload inside the loop waits for vmcnt(0))
-            st[i] = kp_load(reinterpret_cast<const v4i *>(tb + o), nt_loads);
-        }
+            for (int i = N0; i < NV_NST; ++i) {
+                unsigned o = sadr[i - N0] & 0xffffu;        // (opaque: hoisted out of the tile loop these spilled - and a reload
+                asm volatile("" : "+v"(o));                 //  inside the loop waits for vmcnt(0))
+                st[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, AUX));
+            }
+        };
+        if (nt) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 0>{});
     };
     auto stage_write = [&]() {
 #pragma unroll
@@ -1178,7 +1230,8 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         cv[r] = (unsigned)cset[src] | (ok ? 0u : 0x10000u);   // (bit 16: nothing exists there)
     }
     int ltile = g;
-    if (ltile < nlist) stage_load(phys(ltile));
+    const int nt_limit = __builtin_amdgcn_readfirstlane(nt_flag);   // list positions below it are loaded `nt` (lloyd_pass)
+    if (ltile < nlist) stage_load(phys(ltile), ltile < nt_limit);
 #pragma unroll
     for (int r = 0; r < NCS; ++r) cs[tid + 256 * r] = (cv[r] & 0x10000u) ? (uint16_t)0 : (uint16_t)(cv[r] ^ 0x8080u);
     __syncthreads();
@@ -1302,7 +1355,7 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
         stage_write();
         __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        if (ltile + G < nlist) stage_load(phys(ltile + G));   // in flight during the MFMAs
+        if (ltile + G < nlist) stage_load(phys(ltile + G), ltile + G < nt_limit);   // in flight during the MFMAs
         __builtin_amdgcn_s_setprio(0);
 
         const int blk = 4 * tin + wave;
@@ -1595,8 +1648,8 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         // (assign_accumulate with labels: every pixel of the image is labelled, halo rows of a row window included)
         void *lab_out = raster ? raster : static_cast<void *>(labels);
         const int lab_u8 = raster ? raster_u8 : 1;
-        // see kp_load: the bytes a pass streams (a split slab: three quarters of the feature bytes)
-        const int nt_flag = (size_t)B * lo.ntiles * (lo.split ? lo.tile_bytes / 4 * 3 : lo.tile_bytes) >= KP_NT_MIN_SLAB_BYTES ? 1 : 0;
+        // which tile loads carry the nontemporal hint (see kp_nt_limit)
+        const int nt_flag = 0;                                        // the wide-slab kernels load plain
 #define GCS_KP_LAUNCHW(KT_, NST_, DS_, WV_)                                                                              \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NST_, DS_, WV_>), dim3(parts, B), dim3(64 * WV_), 0, stream,         \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,          \
@@ -1606,10 +1659,13 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
         const int nst = (nchunk + 255) / 256;                         // staging chunks per thread (4-wave workgroups)
         if (lo.split) {                                               // (D < 80, at most two levels: csrc/common.h)
             const int rounds = ((lo.S >> 4) + 255) / 256;             // staging rounds: items of 16 slots per thread
+            const int nt_limit = kp_nt_limit(lo, B, n_sets, lo.tile_bytes / 4 * 3);   // (a pass streams 3/4 of a tile's bytes)
+            if ((unsigned long long)lo.img_bytes >= (1ull << 32))    // MID / TOP runs are addressed by 32-bit offsets from the LO run
+                return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large for the split slab's pass");
 #define GCS_KP_LAUNCHS(KT_, NR_)                                                                                            \
     hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NR_, KP_DSTEPS_NARROW, 4, true>), dim3(parts, B), dim3(256), 0, stream, \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,             \
-                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_limit)
             // (measured and dropped, profiles/r6_notes.md: eight waves per workgroup at two workgroups per CU - 0.28 against 0.15 ms
             //  per pass -, the assign A fragments in LDS, the second sub-tile's transposed reads under the first one's epilogue)
             if (k <= 8 && rounds <= 3) { GCS_KP_LAUNCHS(1, 3); }
@@ -1638,10 +1694,11 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
                 // does not fit 168 VGPRs and runs with two workgroups per CU)
                 const int minb = lo.n_levels == 4 && lo.DL[0] != NV_DL ? 2 : GCS_NV_MINB;
                 const int parts_eff = native_parts_eff(B, parts, (long long)lo.ntiles * KP_TP, minb);
+                const int nt_limit = kp_nt_limit(lo, B, n_sets, lo.tile_bytes);
 #define GCS_NV_LAUNCH_(NL_, MINB_, N0_)                                                                                       \
     hipLaunchKernelGGL((kmeans_pass_native_kernel<NL_, MINB_, N0_>), dim3(B, parts), dim3(256), 0, stream,                   \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts, parts_eff,  \
-                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_flag)
+                       reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_limit)
 #define GCS_NV_LAUNCH(NL_, MINB0_)                                          \
     do {                                                                    \
         if (lo.DL[0] == NV_DL) GCS_NV_LAUNCH_(NL_, GCS_NV_MINB, 6);         \
