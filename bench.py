@@ -481,10 +481,10 @@ def main():
         # configuration, reported beside `value` for the record (never `value`)
         log("timing BASELINE config 4 (8x8 bank)")
         seg4 = Segmenter(n_scales=8, n_orient=8, k=args.k, n_iter=args.n_iter, device=dev)
-        for _ in range(3):
+        for _ in range(5):
             seg4.segment_device(imgs, mode=args.mode, out=out)
         torch.cuda.synchronize(dev)
-        n4 = max(3, args.steps // 4)
+        n4 = max(10, args.steps // 2)                      # (3 ms per step: five steps were too short a run to be steady)
         t0 = time.perf_counter()
         for _ in range(n4):
             seg4.segment_device(imgs, mode=args.mode, out=out)
