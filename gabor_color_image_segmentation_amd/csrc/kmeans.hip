@@ -234,7 +234,7 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
 // bytes its predecessor read last: those are worth keeping in the cache; everything before them is evicted before anyone returns
 // and allocating it only costs. The split-slab pass and the deep-bank pass therefore load the list positions below `nt_limit` with
 // the nontemporal hint (buffer_load ... nt) and the last KP_MALL_KEEP_DEFAULT bytes of every sweep plain. Measured, round 6 (same box,
-// two interleaved rounds each; tools/dbg/mall_keep_sweep.sh, profiles/r6_mall_keep_sweep.txt), whole steps of 64 images:
+// two interleaved rounds each; tools/dbg/mall_keep_sweep.sh - then an environment hook, now variant builds -, profiles/r6_mall_keep_sweep.txt), whole steps of 64 images:
 //   deep-bank pass (8x8 bank, 1 265 MB per pass, HBM-bound): every load plain 0.237 - 0.243 ms per pass, step 3 075 - 3 117 Mpix/s;
 //     every load nt 0.220 - 0.223 ms, 3 172; the last 128 / 192 / 256 / 320 / 384 / 512 MB plain: 0.215 - 0.218 / 0.216 - 0.217 /
 //     0.214 - 0.219 / 0.214 - 0.217 / 0.215 - 0.216 / 0.219 - 0.220 ms, step 3 193 - 3 202 / 3 216 - 3 228 / 3 213 - 3 252 /
@@ -247,19 +247,14 @@ __device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
 // load (and two branches around global loads likewise): from that commit until round 6 no pass kernel contained an `nt` load
 // (ISA), whatever the flag said. The cache policy of a raw buffer load is an immediate operand: two instructions that stay two.
 // The wide-slab kernels of kmeans_pass_mfma_kernel (banks outside the BASELINE configurations, -DGCS_NO_SPLIT) load plain.
-constexpr long long KP_MALL_KEEP_DEFAULT = (long long)256 << 20;
-// (tuning hook for same-box runs: GCS_KP_MALL_MB, read once; 0 = every load nt, a huge value = every load plain)
-static long long kp_mall_keep_bytes() {
-    static const long long v = [] {
-        const char *e = getenv("GCS_KP_MALL_MB");
-        return e ? (long long)atoll(e) << 20 : KP_MALL_KEEP_DEFAULT;
-    }();
-    return v;
-}
+#ifndef GCS_KP_MALL_KEEP_MB       // (variant builds for same-box sweeps: 0 = every load nt, a huge value = every load plain)
+#define GCS_KP_MALL_KEEP_MB 256
+#endif
+constexpr long long KP_MALL_KEEP_DEFAULT = (long long)GCS_KP_MALL_KEEP_MB << 20;
 // list positions (per sweep list: the whole batch, or one image with per-image codebooks) below the result are loaded `nt`
 static int kp_nt_limit(const GcsLayout &lo, int B, int n_sets, long long tile_stream_bytes) {
     const long long lists = n_sets == B ? B : 1, nlist = (long long)lo.ntiles * (n_sets == B ? 1 : B);
-    const long long keep_tiles = kp_mall_keep_bytes() / tile_stream_bytes / lists;
+    const long long keep_tiles = KP_MALL_KEEP_DEFAULT / tile_stream_bytes / lists;
     return (int)(nlist > keep_tiles ? nlist - keep_tiles : 0);
 }
 // Logical feature of plane `pl` of level LL, and its inverse, with the level a COMPILE-TIME constant: `lo` is a by-value kernel
