@@ -275,6 +275,8 @@ __device__ __forceinline__ int kp_plane_on_level(const GcsLayout &lo, int c, int
 }
 constexpr int KP_PITCH = KP_TP * 2 + 64;  // bytes per plane row: +64 B = 16 banks per row, so the 4 rows x 64 B of a
                                           // tr_b16 half-wave and the 8 rows of a ds_read_b128 lane group hit distinct banks
+constexpr int KP_P1 = 128 + 48;           // bytes per COMPACT plane row (kmeans_pass_mfma_kernel, CL1: 64 parents + 48 B: the 4 rows x 2 lane groups
+                                          // of a tr_b16 read and the 16 rows of an update read hit distinct 8-byte bank slots; 16-byte aligned)
 constexpr int KP_DSTEPS_NARROW = 5;       // D <= 79  (every 4x6 bank): 80 plane rows, 46 KB LDS, 3 workgroups / CU
 constexpr int KP_DSTEPS_WIDE = 13;        // D <= 207 (the 8x8 bank, D = 192): 208 plane rows, 120 KB LDS, 1 workgroup / CU
 
@@ -442,7 +444,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     }
     __syncthreads();                                   // scratch reads done: the tile buffer is free again
     // the count row (plane D): byte-planes 2D, 2D+1 read as +1 for every pixel of every tile
-    if (tid < KP_TP / 2) reinterpret_cast<unsigned *>(&s_tile[D * KP_PITCH])[tid] = 0x01010101u;
+    // CL1 (round 6, the split narrow pass with k <= 8): level 1 stays COMPACT in LDS - a plane row of level 1 (and every row behind it:
+    // the count row, the padding) is 64 parents in (parent row, block, parent column) order at pitch KP_P1, NOT the 2 x 2 replication
+    // to 256 pixels: a level-1 item then costs what a level-0 item costs (14 instead of 30 VALU instructions, 2 instead of 8
+    // ds_write_b128: the replication was half of a tile's LDS write traffic and made three of the four waves' staging 45 % longer than
+    // the fourth's). What makes it possible: the pixels of a block row lie in LDS as (x0 x2 x4 x6 | x1 x3 x5 x7), which is also the
+    // column order of the assign MFMA and the K order of the update MFMA. The four consecutive elements a lane's address hands to
+    // ds_read_b64_tr_b16 are then four pixels with four DIFFERENT consecutive parents - the parent row itself, read by the lanes of the
+    // even pixels, of the odd pixels and of both fine rows alike -, and the 16 bytes = 8 pixels of an update operand are the parent
+    // row twice (the same 8 bytes read into both halves of the operand).
+    constexpr bool CL1 = SPLIT && KT == 1;
+    const int DL0 = lo.DL[0];
+    auto row_addr = [&](int r) -> int {                     // byte offset of plane row r in s_tile (CL1: rows >= DL0 are compact)
+        return CL1 && r >= DL0 ? DL0 * KP_PITCH + (r - DL0) * KP_P1 : r * KP_PITCH;
+    };
+    if (tid < (CL1 ? 32 : KP_TP / 2)) reinterpret_cast<unsigned *>(&s_tile[row_addr(D)])[tid] = 0x01010101u;   // (a compact row: 64 parents)
     // UPD2 (round 6, the split narrow pass with k <= 8): the update's MFMA rows are (cluster j, byte b), its K slots (pixel, byte) and
     // its columns 16 PLANES - sums[(j, b)][plane] = sel[(j, b)][(px, t)] * X[(px, t)][plane] with sel = the one-hot digit where t == b -,
     // so that the B operand is a plane row AS IT LIES in LDS (8 pixels x (lo, hi) = one 16-byte read, no byte de-interleave: 40 v_perm
@@ -485,7 +501,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             // slots of a plane come in (row, block, column) order (csrc/common.h). Level-0 item: row (ci & 15) >> 1 of blocks
             // 2 (ci & 1), 2 (ci & 1) + 1 of plane ci >> 4: two 16-byte pieces 128 bytes apart. Level-1 item: parent row c1 & 3 of
             // the four blocks of plane c1 >> 2: per block 4 parents = fine rows 2 p, 2 p + 1 = 32 bytes at q * 128 + 32 p.
-            sdst[i] = l1 ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 32]
+            // (CL1: the item is parent row c1 & 3 of the plane's compact row - 16 parents = 32 bytes, blocks 0, 1 | blocks 2, 3)
+            sdst[i] = l1 ? (CL1 ? (int)(size_t)&s_tile[row_addr(lo.row0[1] + (c1 >> 2)) + (c1 & 3) * 32]
+                                : (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 32])
                          : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (ci & 1) * 256 + ((ci & 15) >> 1) * 16];
         else
             sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
@@ -574,10 +592,17 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                         split_hi((unsigned)m[g], (unsigned)t[g], e, o);
                         const unsigned a = (unsigned)v[2 * g], bb = (unsigned)v[2 * g + 1];
                         v4i w;
-                        w[0] = (int)__builtin_amdgcn_perm(e, a, 0x05010400u);
-                        w[1] = (int)__builtin_amdgcn_perm(e, a, 0x07030602u);
-                        w[2] = (int)__builtin_amdgcn_perm(o, bb, 0x05010400u);
-                        w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
+                        if constexpr (CL1) {                                    // (x0 x2 | x4 x6 | x1 x3 | x5 x7)
+                            w[0] = (int)__builtin_amdgcn_perm(e, a, 0x06020400u);
+                            w[1] = (int)__builtin_amdgcn_perm(o, bb, 0x06020400u);
+                            w[2] = (int)__builtin_amdgcn_perm(e, a, 0x07030501u);
+                            w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030501u);
+                        } else {
+                            w[0] = (int)__builtin_amdgcn_perm(e, a, 0x05010400u);
+                            w[1] = (int)__builtin_amdgcn_perm(e, a, 0x07030602u);
+                            w[2] = (int)__builtin_amdgcn_perm(o, bb, 0x05010400u);
+                            w[3] = (int)__builtin_amdgcn_perm(o, bb, 0x07030602u);
+                        }
                         *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 128 * g) = w;
                     }
                 };
@@ -588,6 +613,22 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                     // odd plane's lanes write their two identical pieces in the other order, so that a ds_write_b128 group
                     // covers eight distinct 16-byte columns.
                     const int e16 = ((lane >> 2) & 1) * 16;
+                    if constexpr (CL1) {
+                        // compact: the four parents of a block as they come - two blocks = one 16-byte store, no replication
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            unsigned e, o;                               // e = (A p0, A p1, B p0, B p1), o = (A p2, A p3, B p2, B p3)
+                            split_hi((unsigned)m[j], (unsigned)t[j], e, o);
+                            const unsigned a0 = (unsigned)v[2 * j], a1 = (unsigned)v[2 * j + 1];
+                            v4i w;
+                            w[0] = (int)__builtin_amdgcn_perm(e, a0, 0x05010400u);   // A: parents 0, 1
+                            w[1] = (int)__builtin_amdgcn_perm(o, a0, 0x05030402u);   //    parents 2, 3
+                            w[2] = (int)__builtin_amdgcn_perm(e, a1, 0x07010600u);   // B
+                            w[3] = (int)__builtin_amdgcn_perm(o, a1, 0x07030602u);
+                            *reinterpret_cast<lds_v4i_ptr>(sdst[i] + 16 * j) = w;
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         unsigned e, o;                                   // e = (A p0, A p1, B p0, B p1), o = (A p2, A p3, B p2, B p3)
@@ -675,6 +716,29 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     };
 
     const int un = lane & 15, ug = lane >> 4;             // update operand coordinates
+    // CL1: LDS addresses of the assign's transposed reads (K-step kk, read rd: plane row 16 kk + 8 h + (i16 >> 2) + 4 rd, first
+    // sub-tile) and of the update's operand reads (plane tile pt: row 16 pt + un; first half): a full row holds the lane's pixels at
+    // their place in the tile, a compact row the parent row of the lane's two fine rows (of its fine row: update)
+    unsigned a_tr[KP_DSTEPS][2], a_up[KP_DSTEPS][2];
+    if constexpr (CL1) {
+        const int i16 = lane & 15, pxblk = (lane >> 4) & 1, hh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < KP_DSTEPS; ++kk)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int r = 16 * kk + 8 * hh + (i16 >> 2) + 4 * rd;
+                const int off = r < DL0 ? (wave * 64 + 16 * pxblk + 4 * (i16 & 3)) * 2 : pxblk * 32 + wave * 8;
+                a_tr[kk][rd] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)&s_tile[row_addr(r) + off];
+            }
+#pragma unroll
+        for (int pt = 0; pt < KP_DSTEPS; ++pt) {
+            const int r = 16 * pt + un;
+            const bool full = r < DL0;
+            const int off = full ? (wave * 64 + 8 * ug) * 2 : (ug >> 1) * 32 + wave * 8;
+            a_up[pt][0] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)&s_tile[row_addr(r) + off];
+            a_up[pt][1] = a_up[pt][0] + (full ? 8u : 0u);     // second half of the operand: the next 4 pixels, or the parent row again
+        }
+    }
     const unsigned usel = (un & 1) ? 0x07050301u : 0x06040200u;
     const unsigned eqr = (unsigned)un * 0x01010101u;
     const int cnt_bp = 2 * D;
@@ -788,6 +852,17 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 const unsigned addr = (unsigned)(size_t)&s_tile[(8 * h + (i16 >> 2)) * KP_PITCH +
                                                                 (wave * 64 + sub * 32 + 16 * pxblk + 4 * (i16 & 3)) * 2];
                 v2i fa[KP_DSTEPS], fbv[KP_DSTEPS];
+                if constexpr (CL1) {
+                    // rows of either kind (a_tr: one address per K-step and read, set up before the tile loop); the second 32-pixel
+                    // sub-tile is 64 bytes further in BOTH: 32 pixels of a full row, two parent rows of a compact one
+#pragma unroll
+                    for (int kk = 0; kk < KP_DSTEPS; ++kk)
+                        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\t"
+                                     "ds_read_b64_tr_b16 %1, %3 offset:%c4"
+                                     : "=&v"(fa[kk]), "=&v"(fbv[kk])
+                                     : "v"(a_tr[kk][0]), "v"(a_tr[kk][1]), "i"(sub * 64)
+                                     : "memory");
+                } else
 #pragma unroll
                 for (int kk = 0; kk < KP_DSTEPS; ++kk)       // the DS offset field holds 16 bits: K-step base in the VGPR
                     asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
@@ -830,14 +905,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const int bj = (int)((pb < best ? pb : best) & 15);
             if (h == 0) {
                 // which pixel this slot holds (csrc/common.h): a main block's, or - rarely - an edge strip's
-                int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + (n & 7), xlim = lo.W;
+                // (CL1: MFMA column n is the pixel at place n of the block row order (x0 x2 x4 x6 | x1 x3 x5 x7))
+                const auto col_of = [&](int nn) { return CL1 ? 2 * (nn & 3) + ((nn >> 2) & 1) : nn & 7; };
+                int y = 8 * by + 4 * sub + (n >> 3), x = 8 * bx + col_of(n), xlim = lo.W;
                 if (blk >= lo.nmain) {           // 26 of the 2 426 blocks of a BSD image
                     // the slot coordinates are re-derived from an opaque copy of the lane number: derived from `n` they are
                     // loop invariants, hipcc keeps them in VGPRs across the tile loop and the pass (168 VGPRs for three
                     // workgroups per CU) spills
                     int no = n;
                     asm volatile("" : "+v"(no));
-                    gcs_strip_pixel(lo, blk, 4 * sub + (no >> 3), no & 7, y, x, xlim);
+                    gcs_strip_pixel(lo, blk, 4 * sub + (no >> 3), col_of(no), y, x, xlim);
                 }
                 const bool inimg = blk < lo.nblk && y < lo.H && x < xlim;
                 const bool valid = inimg && y >= row_lo && y < row_hi;      // votes in the sums (halo rows do not)
@@ -876,32 +953,33 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 // tile by tile - five exposed LDS latencies per half - whatever the source order and however many registers are
                 // free (profiles/r6_notes.md); asm loads are invisible to its wait counting, hence the explicit waits.
                 static_assert(DSTEPS == 5, "the update's read batch is written out for five plane tiles");
-                const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)
-                                    &s_tile[un * KP_PITCH + (wave * 64 + hf * 32 + 8 * ug) * 2];
                 v4i bq[DSTEPS];
-                asm volatile("ds_read_b128 %0, %5\n\t"
-                             "ds_read_b128 %1, %5 offset:%c6\n\t"
-                             "ds_read_b128 %2, %5 offset:%c7\n\t"
-                             "ds_read_b128 %3, %5 offset:%c8\n\t"
-                             "ds_read_b128 %4, %5 offset:%c9"
-                             : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bq[4])
-                             : "v"(ba), "i"(16 * KP_PITCH), "i"(32 * KP_PITCH), "i"(48 * KP_PITCH), "i"(64 * KP_PITCH)
-                             : "memory");
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                asm volatile("" : "+v"(bq[0]));
+                // (CL1: two 8-byte reads per plane tile - the halves of a full row's 16 bytes, or a compact row's parent row twice)
+                v2i bl[DSTEPS], bh[DSTEPS];
+#pragma unroll
+                for (int pt = 0; pt < DSTEPS; ++pt)
+                    asm volatile("ds_read_b64 %0, %2 offset:%c4\n\t"
+                                 "ds_read_b64 %1, %3 offset:%c4"
+                                 : "=&v"(bl[pt]), "=&v"(bh[pt])
+                                 : "v"(a_up[pt][0]), "v"(a_up[pt][1]), "i"(hf * 64)
+                                 : "memory");
+#define KP_UPD_TIE(pt_) asm volatile("" : "+v"(bl[pt_]), "+v"(bh[pt_])); bq[pt_] = v4i{bl[pt_][0], bl[pt_][1], bh[pt_][0], bh[pt_][1]}
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                KP_UPD_TIE(0);
                 accu[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[0], accu[0], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-                asm volatile("" : "+v"(bq[1]));
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                KP_UPD_TIE(1);
                 accu[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[1], accu[1], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                asm volatile("" : "+v"(bq[2]));
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                KP_UPD_TIE(2);
                 accu[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[2], accu[2], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-                asm volatile("" : "+v"(bq[3]));
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                KP_UPD_TIE(3);
                 accu[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[3], accu[3], 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("" : "+v"(bq[4]));
+                KP_UPD_TIE(4);
                 accu[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[4], accu[4], 0, 0, 0);
+#undef KP_UPD_TIE
             }
           }
         } else
