@@ -830,6 +830,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
         }
 
         const int blk = 4 * tin + wave;                          // block index inside the image
+        // (CL1; by, bx are scalars) a main block that lies wholly inside the image and the voting rows, on a pass that writes no
+        // label map: the assign epilogue then skips the per-pixel existence tests (12 of its 44 vector instructions per sub-tile)
+        const bool full_blk = CL1 && !raster && blk < lo.nmain && 8 * bx + 8 <= lo.W && 8 * by >= row_lo &&
+                              8 * by + 8 <= (row_hi < lo.H ? row_hi : lo.H);
         // -------- assign: two 32-pixel sub-tiles per wave (rows 4*sub .. 4*sub+3 of the block)
 #pragma unroll
         for (int sub_i = 0; sub_i < ((GCS_ABL & 1) ? 0 : WAVES == 8 ? 1 : 2); ++sub_i) {
@@ -903,6 +907,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1[0] : s1[1];
             const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
             const int bj = (int)((pb < best ? pb : best) & 15);
+            if (h == 0 && CL1 && full_blk) {
+                // (wave-uniform) every pixel of the block exists and votes, and no label map is asked for: nothing to decide
+                s_lab[pl] = (unsigned char)bj;
+            } else
             if (h == 0) {
                 // which pixel this slot holds (csrc/common.h): a main block's, or - rarely - an edge strip's
                 // (CL1: MFMA column n is the pixel at place n of the block row order (x0 x2 x4 x6 | x1 x3 x5 x7))
