@@ -805,6 +805,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     if constexpr (SPLIT) {
         if (ltile < nlist) load_next_split(tile_has_top(0), ltile);
     }
+    // CL1: the lane's four key bases live in registers (the kernel has them to spare since the compact level 1; the wide kernels, at
+    // their 168, read them from LDS in every sub-tile)
+    long long kbase[KT][4];
+    if constexpr (CL1) {
+#pragma unroll
+        for (int mt = 0; mt < KT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) kbase[mt][g4] = s_const[8 * mt + 2 * g4 + (lane >> 5)];
+    }
     KP_PHASE_DECL;
     for (; ltile < nlist; ltile += G) {
         const int tile = phys(ltile);
@@ -895,7 +904,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int u = __mul24(acc[mt][4 * g + 1], 256) + acc[mt][4 * g];
-                    long long key = mad_i64_i32(u, -32, s_const[8 * mt + 2 * g + h]);   // base: LDS broadcast read
+                    long long key = mad_i64_i32(u, -32, CL1 ? kbase[mt][g] : s_const[8 * mt + 2 * g + h]);   // base: registers, or an LDS broadcast read
                     key = mad_i64_i32(acc[mt][4 * g + 2], -2097152, key);
                     best = key < best ? key : best;
                 }
@@ -903,10 +912,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
             const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
-            // after swap(x, x): element 1 holds the upper half's x in lanes 0-31, element 0 the lower half's x in lanes 32-63
-            const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1[0] : s1[1];
-            const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
-            const int bj = (int)((pb < best ? pb : best) & 15);
+            // after swap(x, x): element 0 holds the LOWER half's x in both halves, element 1 the UPPER half's: the minimum of the two
+            // pairs is the pixel's best key in every lane, with no select by half (and only its low word is needed: the label)
+            const long long ka = (long long)(((unsigned long long)s1[0] << 32) | s0[0]);
+            const long long kb = (long long)(((unsigned long long)s1[1] << 32) | s0[1]);
+            const int bj = (int)((kb < ka ? s0[1] : s0[0]) & 15);
             if (h == 0 && CL1 && full_blk) {
                 // (wave-uniform) every pixel of the block exists and votes, and no label map is asked for: nothing to decide
                 s_lab[pl] = (unsigned char)bj;
