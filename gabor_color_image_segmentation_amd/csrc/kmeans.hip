@@ -1515,9 +1515,10 @@ __global__ __launch_bounds__(256, MINB) void kmeans_pass_native_kernel(
             const unsigned blo = (unsigned)best, bhi = (unsigned)((unsigned long long)best >> 32);
             const auto s0 = __builtin_amdgcn_permlane32_swap(blo, blo, false, false);
             const auto s1v = __builtin_amdgcn_permlane32_swap(bhi, bhi, false, false);
-            const unsigned plo = h ? s0[0] : s0[1], phi = h ? s1v[0] : s1v[1];
-            const long long pb = (long long)(((unsigned long long)phi << 32) | plo);
-            const int bj = (int)((pb < best ? pb : best) & 15);
+            // (element 0 = the lower half's best in both halves, element 1 = the upper half's: see kmeans_pass_mfma_kernel)
+            const long long ka = (long long)(((unsigned long long)s1v[0] << 32) | s0[0]);
+            const long long kb2 = (long long)(((unsigned long long)s1v[1] << 32) | s0[1]);
+            const int bj = (int)((kb2 < ka ? s0[1] : s0[0]) & 15);
             if (h == 0) {
                 const int yi = 4 * sub + (n >> 3), xi = n & 7;               // pixel inside the block
                 int y = 8 * by + yi, x = 8 * bx + xi, xlim = lo.W;          // see kmeans_pass_mfma_kernel
