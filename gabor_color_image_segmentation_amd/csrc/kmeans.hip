@@ -458,6 +458,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
     auto row_addr = [&](int r) -> int {                     // byte offset of plane row r in s_tile (CL1: rows >= DL0 are compact)
         return CL1 && r >= DL0 ? DL0 * KP_PITCH + (r - DL0) * KP_P1 : r * KP_PITCH;
     };
+    // CL1: the 16-byte chunks of a full row r are swizzled by (r >> 3 & 1) * 32 bytes (chunk bit 1): the update's operand reads take
+    // 8 bytes per lane from 16 consecutive rows, and rows r, r + 4, r + 8, r + 12 start on the same banks (the pitch is 16 dwords
+    // modulo 64: what the transposed reads want) - four addresses per bank without the swizzle, two with it (tools/design/
+    // lds_bank_model.py rules; SQ_LDS_BANK_CONFLICT). The transposed reads (4 consecutive rows of one aligned group of 8) and the staging
+    // writes (8 lanes = one row) see a uniform shift.
+    auto row_swz = [&](int r) -> int { return CL1 && r < DL0 ? ((r >> 3) & 1) * 32 : 0; };
     if (tid < (CL1 ? 32 : KP_TP / 2)) reinterpret_cast<unsigned *>(&s_tile[row_addr(D)])[tid] = 0x01010101u;   // (a compact row: 64 parents)
     // UPD2 (round 6, the split narrow pass with k <= 8): the update's MFMA rows are (cluster j, byte b), its K slots (pixel, byte) and
     // its columns 16 PLANES - sums[(j, b)][plane] = sel[(j, b)][(px, t)] * X[(px, t)][plane] with sel = the one-hot digit where t == b -,
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
             // (CL1: the item is parent row c1 & 3 of the plane's compact row - 16 parents = 32 bytes, blocks 0, 1 | blocks 2, 3)
             sdst[i] = l1 ? (CL1 ? (int)(size_t)&s_tile[row_addr(lo.row0[1] + (c1 >> 2)) + (c1 & 3) * 32]
                                 : (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 2)) * KP_PITCH + (c1 & 3) * 32])
-                         : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (ci & 1) * 256 + ((ci & 15) >> 1) * 16];
+                         : (int)(size_t)&s_tile[(ci >> 4) * KP_PITCH + (((ci & 1) * 256 + ((ci & 15) >> 1) * 16) ^ row_swz(ci >> 4))];
         else
             sdst[i] = ci < n0 ? (int)(size_t)&s_tile[(ci >> 5) * KP_PITCH + (ci & 31) * 16]
                       : l1    ? (int)(size_t)&s_tile[(lo.row0[1] + (c1 >> 3)) * KP_PITCH + (c1 & 7) * 64]
@@ -727,14 +733,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
                 const int r = 16 * kk + 8 * hh + (i16 >> 2) + 4 * rd;
-                const int off = r < DL0 ? (wave * 64 + 16 * pxblk + 4 * (i16 & 3)) * 2 : pxblk * 32 + wave * 8;
+                const int off = r < DL0 ? ((wave * 64 + 16 * pxblk + 4 * (i16 & 3)) * 2) ^ row_swz(r) : pxblk * 32 + wave * 8;
                 a_tr[kk][rd] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)&s_tile[row_addr(r) + off];
             }
 #pragma unroll
         for (int pt = 0; pt < KP_DSTEPS; ++pt) {
             const int r = 16 * pt + un;
             const bool full = r < DL0;
-            const int off = full ? (wave * 64 + 8 * ug) * 2 : (ug >> 1) * 32 + wave * 8;
+            const int off = full ? ((wave * 64 + 8 * ug) * 2) ^ row_swz(r) : (ug >> 1) * 32 + wave * 8;
             a_up[pt][0] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)&s_tile[row_addr(r) + off];
             a_up[pt][1] = a_up[pt][0] + (full ? 8u : 0u);     // second half of the operand: the next 4 pixels, or the parent row again
         }
