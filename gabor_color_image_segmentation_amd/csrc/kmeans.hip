@@ -323,11 +323,13 @@ extern "C" int gcs_debug_kp_phases(unsigned long long *out) {
 #define KP_PHASE_STORE
 #endif
 
+// L0T (CL1 kernel only): plane tiles (16 rows) known to lie wholly inside level 0 - the launcher passes 2 for banks whose level 0 has 32
+// planes or more (the 4x6 bank: 36), else 0: see the update's operand reads.
 // SPLIT (round 6): the split slab of csrc/common.h (narrow pass only). NST then counts staging ROUNDS: an ITEM = 16 consecutive slots of a
 // tile = 16 low bytes + 8 bytes of MID nibbles (+ 8 bytes of TOP nibbles when the tile's flag word says that one of them is set),
 // unpacked into the same LDS image as the wide slab's: 16 pixels of a level-0 plane row, or the 4 x 4 parents of one block of a
 // level-1 plane, replicated over the block's 64 pixels.
-template <int KT, int NST, int DSTEPS, int WAVES, bool SPLIT = false>
+template <int KT, int NST, int DSTEPS, int WAVES, bool SPLIT = false, int L0T = 0>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                                           : DSTEPS == KP_DSTEPS_NARROW && KT == 1 && NST <= (SPLIT ? 3 : 6) ? GCS_KP_WAVES
                                           : DSTEPS == KP_DSTEPS_NARROW ? 2 : 1)) void kmeans_pass_mfma_kernel(
@@ -977,33 +979,42 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 2
                 // tile by tile - five exposed LDS latencies per half - whatever the source order and however many registers are
                 // free (profiles/r6_notes.md); asm loads are invisible to its wait counting, hence the explicit waits.
                 static_assert(DSTEPS == 5, "the update's read batch is written out for five plane tiles");
+                // (CL1: two 8-byte reads per plane tile - the halves of a full row's 16 bytes, or a compact row's parent row twice. The
+                //  first L0T plane tiles are known to hold full rows only: ONE 16-byte read each, conflict-free with the rows' swizzle
+                //  where the 8-byte reads of 16 consecutive rows cannot do better than two addresses per bank)
                 v4i bq[DSTEPS];
-                // (CL1: two 8-byte reads per plane tile - the halves of a full row's 16 bytes, or a compact row's parent row twice)
                 v2i bl[DSTEPS], bh[DSTEPS];
 #pragma unroll
-                for (int pt = 0; pt < DSTEPS; ++pt)
-                    asm volatile("ds_read_b64 %0, %2 offset:%c4\n\t"
-                                 "ds_read_b64 %1, %3 offset:%c4"
-                                 : "=&v"(bl[pt]), "=&v"(bh[pt])
-                                 : "v"(a_up[pt][0]), "v"(a_up[pt][1]), "i"(hf * 64)
-                                 : "memory");
-#define KP_UPD_TIE(pt_) asm volatile("" : "+v"(bl[pt_]), "+v"(bh[pt_])); bq[pt_] = v4i{bl[pt_][0], bl[pt_][1], bh[pt_][0], bh[pt_][1]}
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                KP_UPD_TIE(0);
-                accu[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[0], accu[0], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                KP_UPD_TIE(1);
-                accu[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[1], accu[1], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                KP_UPD_TIE(2);
-                accu[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[2], accu[2], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                KP_UPD_TIE(3);
-                accu[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[3], accu[3], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                KP_UPD_TIE(4);
-                accu[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[4], accu[4], 0, 0, 0);
-#undef KP_UPD_TIE
+                for (int pt = 0; pt < DSTEPS; ++pt) {
+                    if (pt < L0T)
+                        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(bq[pt]) : "v"(a_up[pt][0]), "i"(hf * 64) : "memory");
+                    else
+                        asm volatile("ds_read_b64 %0, %2 offset:%c4\n\t"
+                                     "ds_read_b64 %1, %3 offset:%c4"
+                                     : "=&v"(bl[pt]), "=&v"(bh[pt])
+                                     : "v"(a_up[pt][0]), "v"(a_up[pt][1]), "i"(hf * 64)
+                                     : "memory");
+                }
+                // reads issued behind plane tile pt's: one per later tile below L0T, two per later tile from L0T on
+#define KP_UPD_YOUNGER(pt_) (((pt_) + 1 < L0T ? L0T - 1 - (pt_) : 0) + 2 * (DSTEPS - ((pt_) + 1 < L0T ? L0T : (pt_) + 1)))
+#define KP_UPD_STEP(pt_)                                                                                  \
+    do {                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KP_UPD_YOUNGER(pt_)) : "memory");                       \
+        if ((pt_) < L0T) {                                                                                \
+            asm volatile("" : "+v"(bq[pt_]));                                                             \
+        } else {                                                                                          \
+            asm volatile("" : "+v"(bl[pt_]), "+v"(bh[pt_]));                                              \
+            bq[pt_] = v4i{bl[pt_][0], bl[pt_][1], bh[pt_][0], bh[pt_][1]};                                \
+        }                                                                                                 \
+        accu[pt_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(oh, bq[pt_], accu[pt_], 0, 0, 0);               \
+    } while (0)
+                KP_UPD_STEP(0);
+                KP_UPD_STEP(1);
+                KP_UPD_STEP(2);
+                KP_UPD_STEP(3);
+                KP_UPD_STEP(4);
+#undef KP_UPD_STEP
+#undef KP_UPD_YOUNGER
             }
           }
         } else
@@ -1760,13 +1771,14 @@ static int lloyd_pass(const uint16_t *feats, const uint16_t *cent, int B, int H,
             const int nt_limit = kp_nt_limit(lo, B, n_sets, lo.tile_bytes / 4 * 3);   // (a pass streams 3/4 of a tile's bytes)
             if ((unsigned long long)lo.img_bytes >= (1ull << 32))    // MID / TOP runs are addressed by 32-bit offsets from the LO run
                 return gcs_fail(GCS_EINVAL, "gcs_kmeans_assign_accumulate: image too large for the split slab's pass");
-#define GCS_KP_LAUNCHS(KT_, NR_)                                                                                            \
-    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NR_, KP_DSTEPS_NARROW, 4, true>), dim3(parts, B), dim3(256), 0, stream, \
+#define GCS_KP_LAUNCHS(KT_, NR_, ...)                                                                                          \
+    hipLaunchKernelGGL((kmeans_pass_mfma_kernel<KT_, NR_, KP_DSTEPS_NARROW, 4, true __VA_OPT__(,) __VA_ARGS__>), dim3(parts, B), dim3(256), 0, stream, \
                        reinterpret_cast<const unsigned char *>(feats), cent, lo, k, n_sets == B ? 1 : 0, parts,             \
                        reverse ? 1 : 0, row_lo, row_hi, partials, lab_out, lab_u8, nt_limit)
             // (measured and dropped, profiles/r6_notes.md: eight waves per workgroup at two workgroups per CU - 0.28 against 0.15 ms
             //  per pass -, the assign A fragments in LDS, the second sub-tile's transposed reads under the first one's epilogue)
-            if (k <= 8 && rounds <= 3) { GCS_KP_LAUNCHS(1, 3); }
+            if (k <= 8 && rounds <= 3 && lo.DL[0] >= 32) { GCS_KP_LAUNCHS(1, 3, 2); }
+            else if (k <= 8 && rounds <= 3) { GCS_KP_LAUNCHS(1, 3); }
             else if (k <= 8) { GCS_KP_LAUNCHS(1, 5); }
             else { GCS_KP_LAUNCHS(2, 5); }
 #undef GCS_KP_LAUNCHS
