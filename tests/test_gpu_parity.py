@@ -667,8 +667,9 @@ def test_randomised_shapes_banks_and_codebooks_against_the_c_oracle(torch_cuda):
     odd orientation counts, ksize 1-15, k 1-16, both codebook modes, constant extreme images): features and labels equal the C
     oracle's bit for bit; since round 6 half of the cases carry full-contrast patches (flagged tiles of the split slab). (400 further
     cases were run once in round 3, 300 - seed 4, with the packed edge strips - in round 4, 400 - seed 11 - in round 6: 210 of them on
-    the split slab, 128 of those with values >= 4096, 96 of those on shapes with packed edge strips; 0 mismatches,
-    profiles/r6_fuzz400.log.)"""
+    the split slab, 128 of those with values >= 4096, 96 of those on shapes with packed edge strips; and on the round's final kernels
+    (compact level 1 in LDS, swizzled rows, buffer loads) 300 + 600 more - seeds 13 and 14, 131 of the 600 on one-level banks -:
+    0 mismatches, profiles/r6_fuzz400.log, r6_fuzz300.log, r6_fuzz600.log.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
