@@ -153,3 +153,34 @@ def test_lds_bank_model_matches_the_deep_bank_kernel_constants():
     assert rows["staging  ds_write_b128 / 2 x b64"] <= 30
     first = subprocess.run([sys.executable, tool, "--first"], capture_output=True, text=True, check=True).stdout
     assert re.search(r"total\s+624", first), first
+
+
+def test_lds_bank_model_of_the_split_slab_pass_matches_its_constants_and_the_measured_conflicts():
+    """tools/design/lds_bank_model_narrow.py restates the LDS accesses of the split-slab Lloyd pass with level 1 kept compact
+    (round 6) against the lane groups the LDS serves. Its pitches and swizzle are the kernel's; the transposed reads, the 16-byte
+    update reads and the label reads are conflict-free; and the three builds of round 6 reproduce what SQ_LDS_BANK_CONFLICT measured
+    per tile (338 / 223 / 165 cycles: profiles/r6_notes.md) within 5 %."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "gabor_color_image_segmentation_amd", "csrc", "kmeans.hip")).read()
+    model = open(os.path.join(root, "tools", "design", "lds_bank_model_narrow.py")).read()
+    assert "constexpr int KP_PITCH = KP_TP * 2 + 64;" in src and "KP_PITCH = KP_TP * 2 + 64" in model
+    assert "constexpr int KP_P1 = 128 + 48;" in src and "KP_P1 = 128 + 48" in model
+    assert "((r >> 3) & 1) * 32" in src and "((r >> 3) & 1) * 32" in model                  # row_swz
+    assert "GCS_KP_LAUNCHS(1, 3, 2)" in src and "L0T = 0 if B64 else 2" in model            # 16-byte reads for two plane tiles
+    tool = os.path.join(root, "tools", "design", "lds_bank_model_narrow.py")
+
+    def run(*flags):
+        out = subprocess.run([sys.executable, tool, *flags], capture_output=True, text=True, check=True).stdout
+        rows = {l[:48].strip(): int(l[48:].split()[0]) for l in out.splitlines() if "extra LDS cycles" in l or l.startswith("total")}
+        return rows
+
+    ships = run()
+    assert ships["assign  ds_read_b64_tr_b16"] == 0 and ships["update  ds_read_b128 (plane tiles of level 0)"] == 0
+    assert ships["update  labels ds_read_b64"] == 0 and ships["update  2 x ds_read_b64"] <= 16
+    for flags, measured in (((), 165), (("--b64",), 223), (("--b64", "--noswz"), 338)):
+        total = run(*flags)["total"]
+        assert abs(total - measured) <= 0.05 * measured, (flags, total, measured)
