@@ -6,7 +6,9 @@
 //                            slab, which keeps pyramid level L at 1/4^L of the pixels: a tile's coarse planes are
 //                            replicated over their 2^L x 2^L blocks while they are staged into LDS. 4x6-style banks
 //                            (at most two levels, D <= 79) read the SPLIT slab: 12 of the 16 bits of every value, the
-//                            last 4 for flagged tiles only (template flag SPLIT).
+//                            last 4 for flagged tiles only (template flag SPLIT); with k <= 8 their level 1 stays COMPACT
+//                            in LDS (CL1: block rows held as even | odd pixels, no replication).
+//   kmeans_pass_native_kernel  the pass for deep banks (BASELINE config 4): every level at its own resolution.
 //   kmeans_assign_kernel     generic pass for D >= 208: exact integer argmin via fp32 byte-digit FMAs (all partial
 //                            sums < 2^24, hence exact), LDS-replicated u32 accumulators.
 //   kmeans_reduce_kernel     element-major partial sums -> int64 sums (+ the centroid update when single-rank).
